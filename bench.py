@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Benchmark of the GP log-likelihood hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg4|cfg2] [--evals-per-gpu E]
+
+metric   : GP log-lik evals/sec (n x n fp64, batched over the hyperparameter grid)
+workload : cfg4 (default) = BASELINE config 4, the configuration the north_star's MFMA
+           target is quoted on: synthetic 5-D design, n = 4096, K = 3 anisotropic
+           components; 64 evaluations per GPU (weak scaling: 8 GPUs = the 512-point grid).
+           cfg2 = Heat-Exchanger grid (Qian n = 64, 624 x 1000 evaluations, sharded by row).
+step     : one pass of the hot path over this rank's batch -- covariance build, Cholesky,
+           solves, log-likelihood for every draw -- followed by the single all-gather of
+           the log-likelihoods (RCCL).  Inputs (X, y, parameter matrix) are resident in HBM
+           before the timed region.
+One rank per GPU; for N > 1 launch through torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+def maximin_lhs(n, d, seed, sweeps=2000):
+    """Seeded random Latin hypercube in [0,1]^d improved by maximin column swaps."""
+    rng = np.random.default_rng(seed)
+    X = np.empty((n, d))
+    for k in range(d):
+        X[:, k] = (rng.permutation(n) + 0.5) / n
+
+    def near(i):
+        dd = ((X - X[i]) ** 2).sum(axis=1)
+        dd[i] = np.inf
+        return dd.min()
+
+    for _ in range(sweeps):
+        a, b = rng.integers(0, n, size=2)
+        k = rng.integers(0, d)
+        if a == b:
+            continue
+        before = min(near(a), near(b))
+        X[a, k], X[b, k] = X[b, k], X[a, k]
+        if min(near(a), near(b)) < before:
+            X[a, k], X[b, k] = X[b, k], X[a, k]
+    return X
+
+
+def cfg4_inputs(total_evals, n=4096, d=5, K=3, seed=20140101):
+    X = maximin_lhs(n, d, seed)
+    y = np.sin(2.0 * np.pi * X).sum(axis=1)
+    rng = np.random.default_rng(seed + 1)
+    P = np.empty((total_evals, K + K * d))
+    for b in range(total_evals):
+        w = 0.15 + 0.55 * rng.dirichlet(np.ones(K))           # weights on the simplex, none negligible
+        th = np.exp(rng.uniform(math.log(0.5), math.log(50.0), size=(K, d)))
+        th[K - 1] = np.maximum(th[K - 1], 20.0)                # roughest component keeps R PD (no nugget)
+        P[b] = np.concatenate([w, th.ravel()])
+    return X, y, P, K
+
+
+def cfg2_inputs():
+    from ccgp_amd.tables import read_table
+    from ccgp_amd import api
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    _, tr = read_table(os.path.join(data, "qian_train.txt"))
+    _, H = read_table(os.path.join(data, "hx_hyperpars_matrix.txt"))
+    X, y = tr[:, :4], tr[:, 4]
+    N = 1000
+    u = api.halton_base2(N)
+    G = H.shape[0]
+    P = np.empty((G * N, 2 + 2 * 4))
+    for g in range(G):
+        th1 = api.qigamma(u, H[g, 0], H[g, 1])
+        th2 = api.qigamma(u, H[g, 2], H[g, 3])
+        blk = P[g * N:(g + 1) * N]
+        blk[:, 0], blk[:, 1] = u, 1.0 - u
+        blk[:, 2:6] = th1[:, None]
+        blk[:, 6:10] = th2[:, None]
+    return X, y, P, 2, float(np.var(y, ddof=1))
+
+
+def update_kernel_flops(n):
+    """Algorithmic flops of the trailing-update launches for ONE matrix: tile (i,j), i > j,
+    needs 2*128^3*j; a diagonal tile needs only its lower half."""
+    nt = (n + 127) // 128
+    t3 = 2.0 * 128 ** 3
+    return sum(j * t3 * ((nt - 1 - j) + 0.5) for j in range(1, nt))
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2, budget_s=20.0):
+    """The oracle (numpy restatement of the reference's R operation sequence: materialised
+    U + t(U) + V temporaries, LU inverse via solve(), then dmnorm's chol + chol2inv) timed on
+    this host's cores.  kind = "port": R itself is not installed anywhere in this pipeline."""
+    from oracle import ccgp_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    d = X.shape[1]
+    done, t0 = 0, time.perf_counter()
+    while True:
+        w, Th = orc.unpack_params(P[done % P.shape[0]], K, d)
+        orc.loglik_general(X, y, w, Th, sigma2, mode, tau2)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 4096:
+            break
+    return {"value": done / el, "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": "%d evaluations of the %s workload (n=%d) through oracle.loglik_general, %.1f s"
+                      % (done, workload, X.shape[0], el)}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2"])
+    ap.add_argument("--evals-per-gpu", type=int, default=64)
+    ap.add_argument("--n", type=int, default=4096, help="cfg4 matrix order (parity/debug runs only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ccgp_amd  # noqa: F401
+    from ccgp_amd import api, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    mode, tau2 = api.MEAN_PROFILE_BETA, 0.0
+    if args.workload == "cfg4":
+        total = args.evals_per_gpu * world
+        X, y, P, K = cfg4_inputs(total, n=args.n)
+        sigma2 = 1.0
+        lo, hi = shard.shard_bounds(total, rank, world)
+        wl_name = "cfg4: synthetic maximin-LHS 5-D design n=%d, K=3 anisotropic components, %d draws/GPU" % (
+            args.n, args.evals_per_gpu)
+    else:
+        X, y, P, K, sigma2 = cfg2_inputs()
+        mode, tau2 = api.MEAN_ZERO_PLUS_TAU2, 50.0 ** 2
+        total = P.shape[0]
+        G = total // 1000
+        glo, ghi = shard.shard_bounds(G, rank, world)     # shard by grid ROW (strong scaling: fixed grid)
+        lo, hi = glo * 1000, ghi * 1000
+        wl_name = "cfg2: Heat-Exchanger grid, Qian n=64, 624 rows x 1000 Halton nodes"
+    n, d = X.shape
+    B = hi - lo
+
+    # inputs resident in HBM (column-major, as the C ABI takes them)
+    f64 = dict(dtype=torch.float64, device=dev)
+    dX = torch.tensor(np.asfortranarray(X).ravel(order="F"), **f64)
+    dy = torch.tensor(y, **f64)
+    dP = torch.tensor(np.asfortranarray(P[lo:hi]).ravel(order="F"), **f64)
+    d_ll = torch.empty(B, **f64)
+    d_beta = torch.empty(B, **f64)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    sizes = shard.shard_sizes(total if args.workload == "cfg4" else total, world)
+    if args.workload == "cfg2":
+        sizes = [1000 * s for s in shard.shard_sizes(total // 1000, world)]
+    gather_buf = [torch.empty(max(sizes), **f64) for _ in range(world)] if world > 1 else None
+    send_buf = torch.zeros(max(sizes), **f64) if world > 1 else None
+
+    h = api.Handle(local)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    h.reserve(n, d, K, max(B, 1), 0)
+
+    def step():
+        h.loglik_batch_dev(dX, n, d, dy, K, dP, B, sigma2, mode, tau2, d_ll, d_beta, d_st)
+        if world > 1:
+            send_buf[:B] = d_ll
+            dist.all_gather(gather_buf, send_buf)          # the one collective of the path
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    h.enable_timing(True)                                  # per-launch HIP events on the kernel's stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing = h.get_timing()
+    h.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], **f64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    bad = int((d_st != 0).sum().item())
+    finite = bool(torch.isfinite(d_ll).all().item())
+
+    if rank == 0:
+        value = total * args.steps / elapsed
+        out = {
+            "metric": "GP log-lik evals/sec (n x n fp64, batched over hyperpar grid)",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak" if args.workload == "cfg4" else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl_name, "n": n, "d": d, "K": K, "evals_total": total,
+                       "evals_per_gpu": B, "parallelism": "grid sharded over %d GPU(s), one all-gather" % world,
+                       "failed_evals": bad, "all_finite": finite},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in timing.items() if v[1]},
+        }
+        if args.workload == "cfg4":
+            upd_ms, upd_launches = timing["update"]
+            flops = update_kernel_flops(n) * B * args.steps          # this rank's launches
+            ach = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "tile_gemm_kernel (mode 0: blocked-Cholesky trailing update)",
+                               "launches": upd_launches,
+                               "avg_launch_ms": upd_ms / max(upd_launches, 1),
+                               "flops_per_launch": flops / max(upd_launches, 1)}
+            out["whole_job_tflops"] = (n ** 3 / 3.0) * total * args.steps / elapsed / 1e12
+        else:
+            fused_ms, fl = timing["fused"]
+            flops = (n ** 3 / 3.0) * B * args.steps
+            ach = flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "small_kernel (fused in-LDS evaluator; latency-bound, see DESIGN.md)",
+                               "launches": fl, "avg_launch_ms": fused_ms / max(fl, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, X, y, P, K, sigma2, mode, tau2)
+        if world == 1 and args.workload == "cfg4" and not args.no_secondary:
+            # secondary line item: the Heat-Exchanger grid (BASELINE config 2) on the same GPU
+            X2, y2, P2, K2, s22 = cfg2_inputs()
+            dX2 = torch.tensor(np.asfortranarray(X2).ravel(order="F"), **f64)
+            dy2 = torch.tensor(y2, **f64)
+            dP2 = torch.tensor(np.asfortranarray(P2).ravel(order="F"), **f64)
+            B2 = P2.shape[0]
+            o1, o2 = torch.empty(B2, **f64), torch.empty(B2, **f64)
+            o3 = torch.zeros(B2, dtype=torch.int32, device=dev)
+            for it in range(3):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                h.loglik_batch_dev(dX2, 64, 4, dy2, K2, dP2, B2, s22, api.MEAN_ZERO_PLUS_TAU2, 2500.0, o1, o2, o3)
+            torch.cuda.synchronize()
+            el2 = (time.perf_counter() - t1) / 2
+            out["secondary"] = {"workload": "cfg2: Heat-Exchanger grid, Qian n=64, 624 x 1000 evals",
+                                "value": B2 / el2, "unit": "evals/s", "ms_per_pass": 1e3 * el2,
+                                "failed_evals": int((o3 != 0).sum().item())}
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,788 @@
+// extern "C" surface of libccgp (include/ccgp.h).  Host orchestration only: argument
+// checks, device scratch, chunking of batches, and the handful of host-side scalars
+// (log-Jacobian, log-prior, quadrature nodes) that the reference computes in R.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "ccgp_internal.h"
+
+using namespace ccgp;
+
+namespace {
+
+#define CCGP_HIP(call)                                                              \
+  do {                                                                              \
+    hipError_t e_ = (call);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+      return CCGP_EHIP;                                                             \
+    }                                                                               \
+  } while (0)
+
+int fail(ccgp_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+int ensure_ws(ccgp_handle* h, size_t bytes) {
+  if (bytes <= h->ws_bytes) return CCGP_OK;
+  if (h->ws) {
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+    CCGP_HIP(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+  }
+  hipError_t e = hipMalloc(&h->ws, bytes);
+  if (e != hipSuccess) {
+    h->ws = nullptr;
+    return fail(h, CCGP_ENOMEM, "device workspace allocation of " + std::to_string(bytes) + " B failed");
+  }
+  h->ws_bytes = bytes;
+  return CCGP_OK;
+}
+
+int ensure_stage(ccgp_handle* h, size_t bytes) {
+  if (bytes <= h->stage_bytes) return CCGP_OK;
+  if (h->stage) {
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+    CCGP_HIP(hipFree(h->stage));
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+  }
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&h->stage, want);
+  if (e != hipSuccess) {
+    h->stage = nullptr;
+    return fail(h, CCGP_ENOMEM, "device staging allocation of " + std::to_string(want) + " B failed");
+  }
+  h->stage_bytes = want;
+  return CCGP_OK;
+}
+
+// bump allocator over the staging buffer (256-byte aligned pieces)
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  static size_t al(size_t b) { return (b + 255) / 256 * 256; }
+  template <class T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off += al(count * sizeof(T));
+    return p;
+  }
+};
+
+bool bad_shape(int n, int d, int K) {
+  return n < 1 || d < 1 || d > kMaxD || K < 1 || K > kMaxK;
+}
+
+// blocked-path chunk size (matrices per pass) under the workspace limit
+int blocked_chunk(const ccgp_handle* h, int npad, int B) {
+  size_t per = blocked_ws_bytes(npad, 1);
+  size_t nb = h->ws_limit / per;
+  if (nb < 1) nb = 1;
+  if (nb > (size_t)B) nb = B;
+  return (int)nb;
+}
+
+int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy, int K,
+               const double* dparams, int B, double sigma2, int mean_mode, double tau2,
+               double* d_loglik, double* d_beta, int* d_status) {
+  if (bad_shape(n, d, K) || B < 0 || !dX || !dy || !dparams || !d_loglik || !d_status)
+    return fail(h, CCGP_EINVAL, "ccgp_loglik_batch: bad argument");
+  if (mean_mode != CCGP_MEAN_PROFILE_BETA && mean_mode != CCGP_MEAN_ZERO_PLUS_TAU2)
+    return fail(h, CCGP_EINVAL, "ccgp_loglik_batch: unknown mean_mode");
+  if (B == 0) return CCGP_OK;
+  DrawView dv{dparams, B, K, d};
+  if (n <= kSmallMaxN) {
+    ScopedTimer t(h, CCGP_T_FUSED);
+    launch_small_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
+                        d_status);
+    CCGP_HIP(hipGetLastError());
+    return CCGP_OK;
+  }
+  const int npad = round_up(n, kTile);
+  if ((size_t)(2 * npad + 6 * kTile + 8) * sizeof(double) > (size_t)kLdsBytes - 64)
+    return fail(h, CCGP_EUNSUPPORTED, "n too large for the single-workgroup forward solve (n <= 9600)");
+  const int nbc = blocked_chunk(h, npad, B);
+  int rc = ensure_ws(h, blocked_ws_bytes(npad, nbc));
+  if (rc) return rc;
+  CCGP_HIP(hipMemsetAsync(d_status, 0, sizeof(int) * (size_t)B, h->stream));
+  for (int b0 = 0; b0 < B; b0 += nbc) {
+    const int nb = std::min(nbc, B - b0);
+    BlockedWs w = blocked_carve(h->ws, npad, nb);
+    blocked_loglik(h, dX, n, d, dy, dv, b0, nb, npad, sigma2, mean_mode, tau2, w, d_loglik, d_beta,
+                   d_status);
+  }
+  CCGP_HIP(hipGetLastError());
+  return CCGP_OK;
+}
+
+int count_bad(const int* status, int B) {
+  int c = 0;
+  for (int i = 0; i < B; ++i) c += status[i] != 0;
+  return c;
+}
+
+// ---- tiny kernels for the literal R.Inv-based helpers (a6, a7, a10, a11) -----------------
+__global__ void rinv_terms_kernel(const double* Rinv, const double* y, int n, double beta,
+                                  double* mean_factor, double* colsum, double* scal) {
+  // one workgroup; scal[0] = 1'Rinv y, scal[1] = sum(Rinv), scal[2] = (y-b)'Rinv(y-b)
+  __shared__ double red[3][4];
+  const int tid = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int j = tid; j < n; j += blockDim.x) {
+    // column j: colSums (apply(R.Inv, 2, sum)); also 1'Rinv y = sum_j colsum_j y_j
+    double cs = 0.0;
+    for (int i = 0; i < n; ++i) cs += Rinv[i + (size_t)j * n];
+    if (colsum) colsum[j] = cs;
+    a0 += cs * y[j];
+    a1 += cs;
+  }
+  for (int i = tid; i < n; i += blockDim.x) {
+    double mf = 0.0;
+    for (int j = 0; j < n; ++j) mf = fma(Rinv[i + (size_t)j * n], y[j] - beta, mf);
+    if (mean_factor) mean_factor[i] = mf;
+    a2 += (y[i] - beta) * mf;
+  }
+  double v[3] = {a0, a1, a2};
+  for (int q = 0; q < 3; ++q) {
+    double x = v[q];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((tid & 63) == 0) red[q][tid >> 6] = x;
+  }
+  __syncthreads();
+  if (tid == 0)
+    for (int q = 0; q < 3; ++q) scal[q] = red[q][0] + red[q][1] + red[q][2] + red[q][3];
+}
+
+__global__ void predict_factors_kernel(const double* r, int m, int n, double beta,
+                                       const double* mean_factor, const double* v1, double v2,
+                                       const double* Rinv, double sigma2, double* mean, double* var) {
+  // one workgroup per test point t; r is m x n column-major (r[t + i*m])
+  __shared__ double red[3][4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  double q = 0.0, s1 = 0.0, sm = 0.0;
+  for (int i = tid; i < n; i += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc = fma(Rinv[i + (size_t)j * n], r[t + (size_t)j * m], acc);
+    const double ri = r[t + (size_t)i * m];
+    q = fma(ri, acc, q);
+    s1 = fma(v1[i], ri, s1);
+    sm = fma(mean_factor[i], ri, sm);
+  }
+  double v[3] = {q, s1, sm};
+  for (int k = 0; k < 3; ++k) {
+    double x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((tid & 63) == 0) red[k][tid >> 6] = x;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double Q = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    double S1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    double SM = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    double u = 1.0 - S1;
+    var[t] = sigma2 * (1.0 - Q + u * u / v2);
+    mean[t] = beta + SM;
+  }
+}
+
+// log-mean-exp of each grid row's N conditional log-likelihoods (likeli.hyperpars, HX:574):
+// logs is laid out [g*N + j]; NaN entries (non-PD draws) propagate as in R's mean().
+__global__ void row_logmeanexp_kernel(const double* logs, int N, int take_log, double* out) {
+  __shared__ double red[4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const double* row = logs + (size_t)g * N;
+  double mx = -INFINITY;
+  bool nan = false;
+  for (int j = tid; j < N; j += blockDim.x) {
+    double v = row[j];
+    if (v != v) nan = true;
+    mx = fmax(mx, v);
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  double s = 0.0;
+  for (int j = tid; j < N; j += blockDim.x) s += exp(row[j] - mx);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  int anynan = __syncthreads_or(nan ? 1 : 0);
+  if (tid == 0) {
+    double tot = red[0] + red[1] + red[2] + red[3];
+    double lme = mx + log(tot / N);
+    double v = take_log ? lme : exp(lme);
+    if (anynan) v = __longlong_as_double(0x7ff8000000000000LL);
+    out[g] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ccgp_version(void) { return "ccgp-mi355x 0.1 (gfx950)"; }
+
+int ccgp_create(int device, ccgp_handle** out) {
+  if (!out) return CCGP_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CCGP_EHIP;
+  if (hipSetDevice(device) != hipSuccess) return CCGP_EHIP;
+  ccgp_handle* h = new ccgp_handle();
+  h->device = device;
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return CCGP_EHIP;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return CCGP_OK;
+}
+
+int ccgp_destroy(ccgp_handle* h) {
+  if (!h) return CCGP_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& s : h->spans) {
+    (void)hipEventDestroy(s.e0);
+    (void)hipEventDestroy(s.e1);
+  }
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->stage) (void)hipFree(h->stage);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return CCGP_OK;
+}
+
+const char* ccgp_last_error(const ccgp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ccgp_set_stream(ccgp_handle* h, void* hip_stream) {
+  if (!h) return CCGP_EINVAL;
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return CCGP_OK;
+}
+
+int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes) {
+  if (!h || bytes < (size_t(1) << 20)) return CCGP_EINVAL;
+  h->ws_limit = bytes;
+  return CCGP_OK;
+}
+
+int ccgp_synchronize(ccgp_handle* h) {
+  if (!h) return CCGP_EINVAL;
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  return CCGP_OK;
+}
+
+int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m) {
+  if (!h || bad_shape(n, d, K) || B < 1 || m < 0) return fail(h, CCGP_EINVAL, "ccgp_reserve: bad argument");
+  CCGP_HIP(hipSetDevice(h->device));
+  if (n > kSmallMaxN) {
+    const int npad = round_up(n, kTile);
+    int rc = ensure_ws(h, blocked_ws_bytes(npad, blocked_chunk(h, npad, B)));
+    if (rc) return rc;
+  }
+  const int P = K + K * d;
+  size_t st = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+              Carver::al(sizeof(double) * (size_t)B * P) + 3 * Carver::al(sizeof(double) * B) +
+              Carver::al(sizeof(double) * (size_t)m * d) + 2 * Carver::al(sizeof(double) * (size_t)B * m) + 4096;
+  return ensure_stage(h, st);
+}
+
+int ccgp_enable_timing(ccgp_handle* h, int on) {
+  if (!h) return CCGP_EINVAL;
+  h->timing = on != 0;
+  h->spans_used = 0;
+  return CCGP_OK;
+}
+
+int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches) {
+  if (!h || id < 0 || id >= CCGP_T_COUNT) return CCGP_EINVAL;
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  double ms = 0.0;
+  int cnt = 0;
+  for (size_t i = 0; i < h->spans_used; ++i) {
+    if (h->spans[i].id != id) continue;
+    float f = 0.f;
+    CCGP_HIP(hipEventElapsedTime(&f, h->spans[i].e0, h->spans[i].e1));
+    ms += f;
+    ++cnt;
+  }
+  if (out_ms) *out_ms = ms;
+  if (out_launches) *out_launches = cnt;
+  return CCGP_OK;
+}
+
+// ---- a1-a5 ------------------------------------------------------------------------------
+static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d,
+                       int K, const double* params_row, double* out, bool gram) {
+  if (!h || bad_shape(n, d, K) || m < 1 || !X || !params_row || !out || (!gram && !Xnew))
+    return fail(h, CCGP_EINVAL, "ccgp_corr_*: bad argument");
+  CCGP_HIP(hipSetDevice(h->device));
+  const int P = K + K * d;
+  size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * (size_t)m * d) +
+                Carver::al(sizeof(double) * P) + Carver::al(sizeof(double) * (size_t)m * n);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dX = c.take<double>((size_t)n * d);
+  double* dXn = c.take<double>((size_t)m * d);
+  double* dp = c.take<double>(P);
+  double* dout = c.take<double>((size_t)m * n);
+  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+  if (!gram)
+    CCGP_HIP(hipMemcpyAsync(dXn, Xnew, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dp, params_row, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+  DrawView dv{dp, 1, K, d};
+  {
+    ScopedTimer t(h, CCGP_T_COV);
+    launch_cov_dense(h->stream, gram ? dX : dXn, m, dX, n, d, dv, 0, dout, m);
+  }
+  CCGP_HIP(hipGetLastError());
+  CCGP_HIP(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  return CCGP_OK;
+}
+
+int ccgp_corr_matrix(ccgp_handle* h, const double* X, int n, int d, const double* theta,
+                     double* out_R) {
+  if (!theta || d < 1 || d > kMaxD) return fail(h, CCGP_EINVAL, "ccgp_corr_matrix: bad argument");
+  std::vector<double> row(1 + d);
+  row[0] = 1.0;
+  for (int k = 0; k < d; ++k) row[1 + k] = theta[k];
+  return corr_common(h, nullptr, n, X, n, d, 1, row.data(), out_R, true);
+}
+
+int ccgp_corr_cross(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d,
+                    const double* theta, double* out) {
+  if (!theta || d < 1 || d > kMaxD) return fail(h, CCGP_EINVAL, "ccgp_corr_cross: bad argument");
+  std::vector<double> row(1 + d);
+  row[0] = 1.0;
+  for (int k = 0; k < d; ++k) row[1 + k] = theta[k];
+  return corr_common(h, Xnew, m, X, n, d, 1, row.data(), out, false);
+}
+
+int ccgp_mixed_corr_matrix(ccgp_handle* h, const double* X, int n, int d, int K,
+                           const double* params, double* out_R) {
+  return corr_common(h, nullptr, n, X, n, d, K, params, out_R, true);
+}
+
+int ccgp_mixed_corr_cross(ccgp_handle* h, const double* Xnew, int m, const double* X, int n,
+                          int d, int K, const double* params, double* out) {
+  return corr_common(h, Xnew, m, X, n, d, K, params, out, false);
+}
+
+// ---- a6, a7, a10 ---------------------------------------------------------------------------
+static int rinv_terms(ccgp_handle* h, const double* R_inv, const double* y, int n, double beta,
+                      double* mean_factor, double* colsum, double scal[3]) {
+  if (!h || n < 1 || !R_inv || !y) return fail(h, CCGP_EINVAL, "R.Inv helper: bad argument");
+  CCGP_HIP(hipSetDevice(h->device));
+  size_t need = Carver::al(sizeof(double) * (size_t)n * n) + 3 * Carver::al(sizeof(double) * n) + 256;
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dR = c.take<double>((size_t)n * n);
+  double* dy = c.take<double>(n);
+  double* dmf = c.take<double>(n);
+  double* dcs = c.take<double>(n);
+  double* dsc = c.take<double>(4);
+  CCGP_HIP(hipMemcpyAsync(dR, R_inv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(rinv_terms_kernel, dim3(1), dim3(256), 0, h->stream, dR, dy, n, beta, dmf, dcs, dsc);
+  CCGP_HIP(hipGetLastError());
+  if (mean_factor) CCGP_HIP(hipMemcpyAsync(mean_factor, dmf, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  if (colsum) CCGP_HIP(hipMemcpyAsync(colsum, dcs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(scal, dsc, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  return CCGP_OK;
+}
+
+int ccgp_beta_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double* out_beta) {
+  if (!out_beta) return fail(h, CCGP_EINVAL, "ccgp_beta_mle: bad argument");
+  double sc[3];
+  int rc = rinv_terms(h, R_inv, y, n, 0.0, nullptr, nullptr, sc);
+  if (rc) return rc;
+  *out_beta = sc[0] / sc[1];
+  return CCGP_OK;
+}
+
+int ccgp_sigma2_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double beta,
+                    double* out_sigma2) {
+  if (!out_sigma2) return fail(h, CCGP_EINVAL, "ccgp_sigma2_mle: bad argument");
+  double sc[3];
+  int rc = rinv_terms(h, R_inv, y, n, beta, nullptr, nullptr, sc);
+  if (rc) return rc;
+  *out_sigma2 = sc[2] / n;
+  return CCGP_OK;
+}
+
+int ccgp_factors(ccgp_handle* h, const double* R_inv, double beta, const double* y, int n,
+                 double* out) {
+  if (!out) return fail(h, CCGP_EINVAL, "ccgp_factors: bad argument");
+  double sc[3];
+  int rc = rinv_terms(h, R_inv, y, n, beta, out, out + n, sc);
+  if (rc) return rc;
+  out[2 * n] = sc[1];
+  return CCGP_OK;
+}
+
+int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, double beta,
+                              const double* mean_factor, const double* var_factor1,
+                              double var_factor2, const double* R_inv, double sigma2,
+                              double* out_mean, double* out_var) {
+  if (!h || m < 1 || n < 1 || !r || !mean_factor || !var_factor1 || !R_inv || !out_mean || !out_var)
+    return fail(h, CCGP_EINVAL, "ccgp_predict_from_factors: bad argument");
+  CCGP_HIP(hipSetDevice(h->device));
+  size_t need = Carver::al(sizeof(double) * (size_t)n * n) + Carver::al(sizeof(double) * (size_t)m * n) +
+                2 * Carver::al(sizeof(double) * n) + 2 * Carver::al(sizeof(double) * m);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dR = c.take<double>((size_t)n * n);
+  double* dr = c.take<double>((size_t)m * n);
+  double* dmf = c.take<double>(n);
+  double* dv1 = c.take<double>(n);
+  double* dmean = c.take<double>(m);
+  double* dvar = c.take<double>(m);
+  CCGP_HIP(hipMemcpyAsync(dR, R_inv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dr, r, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dmf, mean_factor, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dv1, var_factor1, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(predict_factors_kernel, dim3(m), dim3(256), 0, h->stream, dr, m, n, beta, dmf,
+                     dv1, var_factor2, dR, sigma2, dmean, dvar);
+  CCGP_HIP(hipGetLastError());
+  CCGP_HIP(hipMemcpyAsync(out_mean, dmean, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(out_var, dvar, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  return CCGP_OK;
+}
+
+// ---- a8/a9/a12 -------------------------------------------------------------------------------
+int ccgp_loglik_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy, int K,
+                          const double* dparams, int B, double sigma2, int mean_mode, double tau2,
+                          double* d_loglik, double* d_beta, int* d_status) {
+  if (!h) return CCGP_EINVAL;
+  CCGP_HIP(hipSetDevice(h->device));
+  return loglik_dev(h, dX, n, d, dy, K, dparams, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
+                    d_status);
+}
+
+int ccgp_loglik_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                      const double* params, int B, double sigma2, int mean_mode, double tau2,
+                      double* out_loglik, double* out_beta, int* status) {
+  if (!h) return CCGP_EINVAL;
+  if (bad_shape(n, d, K) || B < 0 || !X || !y || !params || !out_loglik)
+    return fail(h, CCGP_EINVAL, "ccgp_loglik_batch: bad argument");
+  if (B == 0) return CCGP_OK;
+  CCGP_HIP(hipSetDevice(h->device));
+  const int P = K + K * d;
+  size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                Carver::al(sizeof(double) * (size_t)B * P) + 2 * Carver::al(sizeof(double) * B) +
+                Carver::al(sizeof(int) * (size_t)B);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dX = c.take<double>((size_t)n * d);
+  double* dy = c.take<double>(n);
+  double* dp = c.take<double>((size_t)B * P);
+  double* dll = c.take<double>(B);
+  double* dbeta = c.take<double>(B);
+  int* dst = c.take<int>(B);
+  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
+  rc = loglik_dev(h, dX, n, d, dy, K, dp, B, sigma2, mean_mode, tau2, dll, dbeta, dst);
+  if (rc) return rc;
+  std::vector<int> st(B);
+  CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
+  return count_bad(st.data(), B);
+}
+
+int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                           const double* params, int B, double sigma2, double* out_loglik,
+                           double* out_beta, double* out_grad, int* status) {
+  if (!h) return CCGP_EINVAL;
+  if (bad_shape(n, d, K) || B < 1 || !X || !y || !params || !out_grad)
+    return fail(h, CCGP_EINVAL, "ccgp_loglik_grad_batch: bad argument");
+  if (n > kSmallMaxN)
+    return fail(h, CCGP_EUNSUPPORTED, "ccgp_loglik_grad_batch: n > 128 not implemented yet");
+  CCGP_HIP(hipSetDevice(h->device));
+  const int P = K + K * d;
+  const int nch = small_grad_chunks(n, d);
+  size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                2 * Carver::al(sizeof(double) * (size_t)B * P) + 2 * Carver::al(sizeof(double) * B) +
+                Carver::al(sizeof(int) * (size_t)B) + Carver::al(sizeof(double) * (size_t)B * nch * P);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dX = c.take<double>((size_t)n * d);
+  double* dy = c.take<double>(n);
+  double* dp = c.take<double>((size_t)B * P);
+  double* dg = c.take<double>((size_t)B * P);
+  double* dll = c.take<double>(B);
+  double* dbeta = c.take<double>(B);
+  int* dst = c.take<int>(B);
+  double* dgp = c.take<double>((size_t)B * nch * P);
+  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
+  DrawView dv{dp, B, K, d};
+  {
+    ScopedTimer t(h, CCGP_T_FUSED);
+    launch_small_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst, dgp);
+  }
+  CCGP_HIP(hipGetLastError());
+  std::vector<int> st(B);
+  if (out_loglik) CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(out_grad, dg, sizeof(double) * (size_t)B * P, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
+  return count_bad(st.data(), B);
+}
+
+// ---- a8: logpost ------------------------------------------------------------------------------
+int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2,
+                 int prior_id, const double* theta_t, const double* prior_pars, double* out_val,
+                 double* out_beta, double* out_loglik, double* out_Rinv, int* status) {
+  if (!h) return CCGP_EINVAL;
+  if (n < 1 || d < 1 || d > kMaxD || !X || !y || !theta_t || !out_val)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost: bad argument");
+  if (prior_id < CCGP_PRIOR_INVGAMMA || prior_id > CCGP_PRIOR_ANI)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost: unknown prior_id");
+  if (prior_id == CCGP_PRIOR_INVGAMMA && !prior_pars)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost: prior_pars required for CCGP_PRIOR_INVGAMMA");
+  if (prior_id == CCGP_PRIOR_ANI && d != 2)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost: the anisotropic script (ANI) is 2-D");
+  const double psi1 = theta_t[0], psi2 = theta_t[1], phi = theta_t[2];
+  const double theta1 = std::exp(psi1), theta2 = std::exp(psi2);
+  const double p = 1.0 / (1.0 + std::exp(-phi));
+  const int K = 2, P = K + K * d;
+  std::vector<double> row(P);
+  row[0] = p;
+  row[1] = 1.0 - p;
+  double log_jacob = -phi - 2.0 * std::log(1.0 + std::exp(-phi)) + psi1 + psi2;
+  double log_prior = 0.0;
+  if (prior_id == CCGP_PRIOR_ANI) {
+    const double zeta = theta_t[3], lambda = std::exp(zeta);
+    row[2] = theta1; row[3] = theta2;
+    row[4] = (1.0 + lambda) * theta1; row[5] = (1.0 + lambda) * theta2;
+    log_jacob += zeta;
+    log_prior = -psi1 - psi1 * psi1 / 2.0 - psi2 - psi2 * psi2 / 2.0 - 4.0 * zeta - 4.0 / lambda;
+  } else {
+    for (int k = 0; k < d; ++k) { row[2 + k] = theta1; row[2 + d + k] = theta2; }
+    if (prior_id == CCGP_PRIOR_INVGAMMA)
+      log_prior = -(prior_pars[0] + 1.0) * psi1 - prior_pars[1] / theta1 -
+                  (prior_pars[2] + 1.0) * psi2 - prior_pars[3] / theta2;
+    else if (prior_id == CCGP_PRIOR_GV)
+      log_prior = -4.0 * psi1 - 1.0 / theta1 - 6.0 * psi2 - 75.0 / theta2;
+    else
+      log_prior = -4.0 * psi1 - 2.0 / theta1 - 6.0 * psi2 - 16.0 / theta2;
+  }
+  double ll = 0.0, beta = 0.0;
+  int st = 0;
+  int rc = ccgp_loglik_batch(h, X, n, d, y, K, row.data(), 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0,
+                             &ll, &beta, &st);
+  if (rc < 0) return rc;
+  if (out_Rinv) {
+    if (n > kSmallMaxN)
+      return fail(h, CCGP_EUNSUPPORTED, "ccgp_logpost: R.Inv output for n > 128 not implemented yet");
+    size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * P) +
+                  Carver::al(sizeof(double) * (size_t)n * n) + 256;
+    int rc2 = ensure_stage(h, need);
+    if (rc2) return rc2;
+    Carver c(h->stage);
+    double* dX = c.take<double>((size_t)n * d);
+    double* dp = c.take<double>(P);
+    double* dR = c.take<double>((size_t)n * n);
+    int* dst = c.take<int>(1);
+    CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemcpyAsync(dp, row.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+    DrawView dv{dp, 1, K, d};
+    {
+      ScopedTimer t(h, CCGP_T_FUSED);
+      launch_small_inverse(h->stream, dX, n, d, dv, 0, dR, dst);
+    }
+    CCGP_HIP(hipGetLastError());
+    CCGP_HIP(hipMemcpyAsync(out_Rinv, dR, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+  }
+  *out_val = ll + log_jacob + log_prior;
+  if (out_beta) *out_beta = beta;
+  if (out_loglik) *out_loglik = ll;
+  if (status) *status = st;
+  return st != 0 ? 1 : 0;
+}
+
+// ---- a9: hyperprior grid ------------------------------------------------------------------------
+int ccgp_halton_base2(int N, double* out) {
+  if (N < 0 || !out) return CCGP_EINVAL;
+  halton_base2(N, out);
+  return CCGP_OK;
+}
+
+int ccgp_qigamma(const double* p, int N, double alpha, double beta, double* out) {
+  if (N < 0 || !p || !out || !(alpha > 0.0) || !(beta > 0.0)) return CCGP_EINVAL;
+  for (int i = 0; i < N; ++i) out[i] = qigamma(p[i], alpha, beta);
+  return CCGP_OK;
+}
+
+int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const double* y,
+                       double sigma2, const double* hyper, int G, int N, double tau, int take_log,
+                       double aniso_lambda, double* out, int* out_argmax, double* out_logs) {
+  if (!h) return CCGP_EINVAL;
+  if (n < 1 || d < 1 || d > kMaxD || G < 1 || N < 1 || !X || !y || !hyper || !out)
+    return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: bad argument");
+  const bool aniso = aniso_lambda >= 0.0;
+  if (aniso && d != 2) return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: anisotropic kernel is 2-D");
+  CCGP_HIP(hipSetDevice(h->device));
+  const int K = 2, P = K + K * d;
+  const size_t B = (size_t)G * N;
+  if (B > (size_t)1 << 30) return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: G*N too large");
+  std::vector<double> u(N);
+  halton_base2(N, u.data());
+  // unit-rate gamma quantiles per distinct shape (the same Halton node drives p, theta1, theta2)
+  std::map<double, std::vector<double>> qcache;
+  auto quant = [&](double alpha) -> const std::vector<double>& {
+    auto it = qcache.find(alpha);
+    if (it != qcache.end()) return it->second;
+    std::vector<double> q(N);
+    for (int j = 0; j < N; ++j) q[j] = qgamma_unit(1.0 - u[j], alpha);
+    return qcache.emplace(alpha, std::move(q)).first->second;
+  };
+  std::vector<double> params(B * P);
+  for (int g = 0; g < G; ++g) {
+    const double a1 = hyper[g], b1 = hyper[g + (size_t)G], a2 = hyper[g + (size_t)2 * G],
+                 b2 = hyper[g + (size_t)3 * G];
+    if (!(a1 > 0.0) || !(b1 > 0.0) || !(a2 > 0.0) || !(b2 > 0.0))
+      return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: hyperparameters must be positive");
+    const std::vector<double>& q1 = quant(a1);
+    const std::vector<double>& q2 = quant(a2);
+    for (int j = 0; j < N; ++j) {
+      const size_t b = (size_t)g * N + j;
+      const double p = u[j], th1 = b1 / q1[j], th2 = b2 / q2[j];
+      params[b] = p;
+      params[b + B] = 1.0 - p;
+      if (aniso) {
+        params[b + 2 * B] = th1;
+        params[b + 3 * B] = th2;
+        params[b + 4 * B] = (1.0 + aniso_lambda) * th1;
+        params[b + 5 * B] = (1.0 + aniso_lambda) * th2;
+      } else {
+        for (int k = 0; k < d; ++k) {
+          params[b + (size_t)(2 + k) * B] = th1;
+          params[b + (size_t)(2 + d + k) * B] = th2;
+        }
+      }
+    }
+  }
+  size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                Carver::al(sizeof(double) * B * P) + 2 * Carver::al(sizeof(double) * B) +
+                Carver::al(sizeof(int) * B) + Carver::al(sizeof(double) * G);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dX = c.take<double>((size_t)n * d);
+  double* dy = c.take<double>(n);
+  double* dp = c.take<double>(B * P);
+  double* dll = c.take<double>(B);
+  double* dbeta = c.take<double>(B);
+  int* dst = c.take<int>(B);
+  double* dout = c.take<double>(G);
+  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dp, params.data(), sizeof(double) * B * P, hipMemcpyHostToDevice, h->stream));
+  rc = loglik_dev(h, dX, n, d, dy, K, dp, (int)B, sigma2, CCGP_MEAN_ZERO_PLUS_TAU2, tau * tau, dll,
+                  dbeta, dst);
+  if (rc) return rc;
+  hipLaunchKernelGGL(row_logmeanexp_kernel, dim3(G), dim3(256), 0, h->stream, dll, N, take_log, dout);
+  CCGP_HIP(hipGetLastError());
+  CCGP_HIP(hipMemcpyAsync(out, dout, sizeof(double) * G, hipMemcpyDeviceToHost, h->stream));
+  if (out_logs) CCGP_HIP(hipMemcpyAsync(out_logs, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  std::vector<int> st(B);
+  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (out_argmax) {
+    // which.max: first maximum, NaN skipped
+    int best = -1;
+    for (int g = 0; g < G; ++g)
+      if (out[g] == out[g] && (best < 0 || out[g] > out[best])) best = g;
+    *out_argmax = best;
+  }
+  return count_bad(st.data(), (int)B);
+}
+
+// ---- a10/a11: prediction -------------------------------------------------------------------------
+int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy, int K,
+                           const double* dparams, int S, const double* dXtest, int m,
+                           double sigma2, double* d_mean, double* d_var, double* d_beta,
+                           int* d_status) {
+  if (!h) return CCGP_EINVAL;
+  if (bad_shape(n, d, K) || S < 1 || m < 1 || !dX || !dy || !dparams || !dXtest || !d_mean || !d_var)
+    return fail(h, CCGP_EINVAL, "ccgp_predict_batch: bad argument");
+  if (n > kSmallMaxN)
+    return fail(h, CCGP_EUNSUPPORTED, "ccgp_predict_batch: n > 128 not implemented yet");
+  CCGP_HIP(hipSetDevice(h->device));
+  DrawView dv{dparams, S, K, d};
+  {
+    ScopedTimer t(h, CCGP_T_FUSED);
+    launch_small_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
+                         d_status);
+  }
+  CCGP_HIP(hipGetLastError());
+  return CCGP_OK;
+}
+
+int ccgp_predict_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                       const double* params, int S, const double* Xtest, int m, double sigma2,
+                       double* out_mean, double* out_var, double* out_beta, int* status) {
+  if (!h) return CCGP_EINVAL;
+  if (bad_shape(n, d, K) || S < 1 || m < 1 || !X || !y || !params || !Xtest || !out_mean || !out_var)
+    return fail(h, CCGP_EINVAL, "ccgp_predict_batch: bad argument");
+  CCGP_HIP(hipSetDevice(h->device));
+  const int P = K + K * d;
+  size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                Carver::al(sizeof(double) * (size_t)S * P) + Carver::al(sizeof(double) * (size_t)m * d) +
+                2 * Carver::al(sizeof(double) * (size_t)S * m) + Carver::al(sizeof(double) * S) +
+                Carver::al(sizeof(int) * (size_t)S);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dX = c.take<double>((size_t)n * d);
+  double* dy = c.take<double>(n);
+  double* dp = c.take<double>((size_t)S * P);
+  double* dXt = c.take<double>((size_t)m * d);
+  double* dmean = c.take<double>((size_t)S * m);
+  double* dvar = c.take<double>((size_t)S * m);
+  double* dbeta = c.take<double>(S);
+  int* dst = c.take<int>(S);
+  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)S * P, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dXt, Xtest, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice, h->stream));
+  rc = ccgp_predict_batch_dev(h, dX, n, d, dy, K, dp, S, dXt, m, sigma2, dmean, dvar, dbeta, dst);
+  if (rc) return rc;
+  std::vector<int> st(S);
+  CCGP_HIP(hipMemcpyAsync(out_mean, dmean, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(out_var, dvar, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));
+  if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * S, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)S);
+  return count_bad(st.data(), S);
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Internal declarations shared by the HIP translation units of libccgp (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ccgp.h"
+
+namespace ccgp {
+
+constexpr int kTile = 128;       // block size of the blocked Cholesky (rows/cols per tile)
+constexpr int kSmallMaxN = 128;  // n <= this goes to the fused in-LDS evaluator
+constexpr int kMaxD = 64;        // input dimensions supported by the covariance kernels
+constexpr int kMaxK = 8;         // component GPs per draw
+constexpr int kLdsBytes = 160 * 1024;
+
+// one timed launch group: events are recorded on the handle's stream and only read back
+// (hipEventElapsedTime) in ccgp_get_timing, so timing never synchronises the pipeline.
+struct TimedSpan {
+  int id;
+  hipEvent_t e0, e1;
+};
+
+}  // namespace ccgp
+
+struct ccgp_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  size_t ws_limit = size_t(24) << 30;
+  // grow-only device scratch
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // small staging buffers for the host-pointer entry points
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  std::string err;
+  bool timing = false;
+  std::vector<ccgp::TimedSpan> spans;
+  size_t spans_used = 0;
+};
+
+namespace ccgp {
+
+// Layout of one draw on the device: column-major B x P, element (b, j) at params[b + j*ldp].
+struct DrawView {
+  const double* params;
+  int ldp;  // = B
+  int K;
+  int d;
+};
+
+// ---- cov.hip -------------------------------------------------------------------------
+// Dense cross / Gram matrix for ONE draw: out[t + i*ldo], t in [0,m) rows of A (m x d),
+// i in [0,n) rows of Bm (n x d).  normalise: divide by sum w^2 (Mixed.corr.*).
+void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, int n, int d,
+                      DrawView dv, int draw, double* out, int ldo);
+
+// Batched lower-triangle tile writer for the blocked path: for draw b0+z, writes
+// s*R_mixed + t into the lower tiles of an npad x npad column-major matrix (identity on
+// the padding), z in [0, nb).  scale/shift: mode 0 -> (1, 0); mode 1 -> (sigma2*sum w^2, tau2).
+void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
+                      double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
+                      double tau2);
+
+// ---- small.hip -----------------------------------------------------------------------
+// Fused evaluator: one workgroup per draw (and per test-point chunk when m > 0).
+size_t small_lds_bytes(int n, int d, int mtile);
+int small_pick_mtile(int n, int d, int m);
+void launch_small_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
+                         int B, double sigma2, int mean_mode, double tau2, double* loglik,
+                         double* beta, int* status);
+void launch_small_predict(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
+                          int S, const double* Xtest, int m, double sigma2, double* mean,
+                          double* var, double* beta, int* status);
+// Explicit inverse (solve(R), HX:454) and gradient for small n.
+void launch_small_inverse(hipStream_t s, const double* X, int n, int d, DrawView dv, int draw,
+                          double* Rinv, int* status);
+int small_grad_chunks(int n, int d);
+// gpart: scratch of B * small_grad_chunks(n, d) * P doubles
+void launch_small_grad(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
+                       int B, double sigma2, double* loglik, double* beta, double* grad,
+                       int* status, double* gpart);
+
+// ---- blocked.hip ---------------------------------------------------------------------
+struct BlockedWs {
+  double* A;        // nb x npad x npad (lower tiles used)
+  double* invd;     // nb x nt x 128 x 128 inverses of the diagonal blocks
+  double* z;        // nb x 2 x npad forward-solve vectors (y, 1)
+  size_t a_stride;  // elements between consecutive matrices
+};
+size_t blocked_ws_bytes(int npad, int nb);
+BlockedWs blocked_carve(void* ws, int npad, int nb);
+// factorise nb matrices in place and finish the likelihood; loglik/beta/status are
+// indexed from draw b0.
+void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
+                    int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
+                    BlockedWs w, double* loglik, double* beta, int* status);
+
+// ---- special.cpp ---------------------------------------------------------------------
+void halton_base2(int N, double* out);
+double qgamma_unit(double p, double shape);  // quantile of Gamma(shape, rate 1)
+double qigamma(double p, double alpha, double beta);
+
+// ---- helpers -------------------------------------------------------------------------
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct ScopedTimer {
+  ccgp_handle* h;
+  TimedSpan* sp = nullptr;
+  ScopedTimer(ccgp_handle* hh, int id) : h(hh) {
+    if (!h->timing) return;
+    if (h->spans_used == h->spans.size()) {
+      TimedSpan t{};
+      (void)hipEventCreate(&t.e0);
+      (void)hipEventCreate(&t.e1);
+      h->spans.push_back(t);
+    }
+    sp = &h->spans[h->spans_used++];
+    sp->id = id;
+    (void)hipEventRecord(sp->e0, h->stream);
+  }
+  ~ScopedTimer() {
+    if (sp) (void)hipEventRecord(sp->e1, h->stream);
+  }
+};
+
+}  // namespace ccgp

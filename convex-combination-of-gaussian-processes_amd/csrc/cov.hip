@@ -1,0 +1,148 @@
+// Covariance / convex-combination kernels.
+//
+// Reference arithmetic: corr.matrix HX:328-337 / ANI:351-360, corr.matrix.ISO HX:347-356,
+// corr.vec(.ISO) HX:367-375 / ANI:369-377, Mixed.corr.matrix HX:408-415 / ANI:399-406,
+// Mixed.corr.vec HX:425-431.  The reference's EXPANDED distance is kept:
+//   dist_c(i,j) = (u_ci + u_cj) - 2 sum_k (x_ik theta_ck) x_jk,   u_ci = sum_k theta_ck x_ik^2
+// (HX:352-355), so the diagonal is exp(-rounding) exactly as in R, not a forced 1.
+//
+// Roofline: HBM-bound on the output write when the matrix is materialised
+// (8 n^2 B dense, 4 n^2 B lower tiles) -- X (n x d) is read once per tile into LDS and
+// every output column is written as 512 B contiguous per wave (lane = row).
+#include "ccgp_internal.h"
+
+namespace ccgp {
+
+namespace {
+
+constexpr int kCovRows = 64;   // rows per workgroup tile (one per lane)
+constexpr int kCovCols = 64;   // columns per workgroup tile (16 per wave)
+
+struct CovArgs {
+  const double* A;   // m x d column-major (rows of the output)
+  const double* Bm;  // n x d column-major (columns of the output)
+  int m, n, d;
+  const double* params;
+  int ldp, K;
+  int draw0;
+  double* out;
+  size_t batch_stride;
+  int ldo;
+  int mode;  // 0: normalised R_mixed; 1: sigma2*sum(w^2)*R_mixed + tau2
+  double sigma2, tau2;
+  int lower_tiles;  // 1: square, write only tiles with row-tile >= col-tile, pad identity to npad
+  int npad;
+};
+
+// LDS: xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
+__global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int d = a.d, K = a.K;
+  double* xa = smem;
+  double* xb = xa + d * kCovRows;
+  double* ua = xb + d * kCovCols;
+  double* ub = ua + K * kCovRows;
+  double* th = ub + K * kCovCols;
+  double* w2 = th + K * d;
+
+  int tr = blockIdx.x, tc = blockIdx.y;
+  if (a.lower_tiles) {
+    // triangular launch: blockIdx.x enumerates (tr >= tc) pairs of 64-wide tiles
+    int t = blockIdx.x;
+    int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    while (r * (r + 1) / 2 > t) --r;
+    tr = r;
+    tc = t - r * (r + 1) / 2;
+  }
+  const int b = a.draw0 + blockIdx.z;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i0 = tr * kCovRows, j0 = tc * kCovCols;
+
+  for (int e = tid; e < K * d; e += 256) th[e] = a.params[b + (size_t)(K + e) * a.ldp];
+  if (tid < K) {
+    double w = a.params[b + (size_t)tid * a.ldp];
+    w2[tid] = w * w;
+  }
+  for (int e = tid; e < d * kCovRows; e += 256) {
+    int k = e / kCovRows, r = e % kCovRows;
+    int gi = i0 + r;
+    xa[e] = gi < a.m ? a.A[gi + (size_t)k * a.m] : 0.0;
+    int gj = j0 + r;
+    xb[e] = gj < a.n ? a.Bm[gj + (size_t)k * a.n] : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < K * kCovRows; e += 256) {
+    int c = e / kCovRows, r = e % kCovRows;
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < d; ++k) {
+      double t = th[c * d + k];
+      double va = xa[k * kCovRows + r], vb = xb[k * kCovCols + r];
+      sa += va * va * t;  // (X^2 %*% Theta) row sums
+      sb += vb * vb * t;
+    }
+    ua[e] = sa;
+    ub[e] = sb;
+  }
+  __syncthreads();
+
+  double sw = 0.0;
+  for (int c = 0; c < K; ++c) sw += w2[c];
+  const double post_scale = a.mode == 1 ? a.sigma2 * sw : 1.0;
+  const double post_shift = a.mode == 1 ? a.tau2 : 0.0;
+
+  double* out = a.out + (size_t)blockIdx.z * a.batch_stride;
+  const int gi = i0 + lane;
+  const int rows_valid = a.lower_tiles ? a.npad : a.m;
+  const int cols_valid = a.lower_tiles ? a.npad : a.n;
+  for (int jj = 0; jj < kCovCols / 4; ++jj) {
+    const int jl = wave * (kCovCols / 4) + jj;
+    const int gj = j0 + jl;
+    if (gj >= cols_valid) break;
+    double acc = 0.0;
+    for (int c = 0; c < K; ++c) {
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) s = fma(xa[k * kCovRows + lane] * th[c * d + k], xb[k * kCovCols + jl], s);
+      double dist = (ua[c * kCovRows + lane] + ub[c * kCovCols + jl]) + (-2.0 * s);
+      acc += w2[c] * exp(-dist);
+    }
+    double v = acc / sw;
+    v = post_scale * v + post_shift;
+    if (a.lower_tiles) {
+      if (gi >= a.n || gj >= a.n) v = (gi == gj) ? 1.0 : 0.0;  // identity padding
+    }
+    if (gi < rows_valid) out[gi + (size_t)gj * a.ldo] = v;
+  }
+}
+
+size_t cov_lds(int d, int K) {
+  return sizeof(double) * (size_t)(2 * d * 64 + 2 * K * 64 + K * d + K);
+}
+
+}  // namespace
+
+void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, int n, int d,
+                      DrawView dv, int draw, double* out, int ldo) {
+  CovArgs a{};
+  a.A = A; a.Bm = Bm; a.m = m; a.n = n; a.d = d;
+  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = draw;
+  a.out = out; a.batch_stride = 0; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
+  dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, 1);
+  hipLaunchKernelGGL(cov_kernel, grid, dim3(256), cov_lds(d, dv.K), s, a);
+}
+
+void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
+                      double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
+                      double tau2) {
+  CovArgs a{};
+  a.A = X; a.Bm = X; a.m = n; a.n = n; a.d = d;
+  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = b0;
+  a.out = Abase; a.batch_stride = batch_stride; a.ldo = npad; a.mode = mean_mode;
+  a.sigma2 = sigma2; a.tau2 = tau2; a.lower_tiles = 1; a.npad = npad;
+  int nt64 = npad / 64;
+  dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
+  hipLaunchKernelGGL(cov_kernel, grid, dim3(256), cov_lds(d, dv.K), s, a);
+}
+
+}  // namespace ccgp

@@ -1,0 +1,194 @@
+"""The reference's R function surface on top of libccgp (drop-in boundary).
+
+Same function names (dots become underscores), argument order, argument meaning and
+return shapes as the R scripts, so that parity tests read like the reference's own
+calls.  Each script re-defines the same ~12 functions with a different kernel / prior,
+so the surface is a class parameterised by the script it mirrors:
+
+    gp = CombinedGP("HX")            # Heat Exchanger Emulator/Combined GP Heat Exchanger.R
+    gp.logpost(D_train, theta, y, sigma2, theta1_pars, theta2_pars)  -> dict(val, beta, R_Inv)
+
+Nothing numerical happens here: every method packs arguments and calls the C ABI
+(api.Handle).  Error behaviour follows the reference: a covariance that cannot be
+factorised gives NaN / None where R gives NA (HX:454-455) instead of raising.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import api
+
+_SCRIPTS = {
+    # kernel, prior id, number of transformed parameters, grid (N, tau, take_log)
+    "HX": dict(aniso=False, prior=api.PRIOR_INVGAMMA, npar=3, N=1000, tau=50.0, take_log=True),
+    "ADV": dict(aniso=False, prior=api.PRIOR_INVGAMMA, npar=3, N=1728, tau=100.0, take_log=False),
+    "GV": dict(aniso=False, prior=api.PRIOR_GV, npar=3),
+    "ISO": dict(aniso=False, prior=api.PRIOR_ISO, npar=3),
+    "BSQ": dict(aniso=False, prior=api.PRIOR_ISO, npar=3),
+    "ANI": dict(aniso=True, prior=api.PRIOR_ANI, npar=4),
+}
+
+
+def pack_iso(p, theta1, theta2, d):
+    """(p, theta1, theta2) -> C-ABI row (w1, w2, theta_1k.., theta_2k..), HX:408-415."""
+    return np.concatenate([[p, 1.0 - p], np.full(d, float(theta1)), np.full(d, float(theta2))])
+
+
+def pack_aniso(p, theta1, theta2, lam):
+    """ANI:399-406: component 2 uses (1+lambda)(theta1, theta2)."""
+    return np.array([p, 1.0 - p, theta1, theta2, (1.0 + lam) * theta1, (1.0 + lam) * theta2], dtype=np.float64)
+
+
+class CombinedGP:
+    def __init__(self, script="HX", handle=None, device=0):
+        if script not in _SCRIPTS:
+            raise ValueError("script must be one of %s" % sorted(_SCRIPTS))
+        self.script = script
+        self.cfg = _SCRIPTS[script]
+        self.h = handle if handle is not None else api.Handle(device)
+
+    # ------------------------------------------------------------------ a1 / a2 / a3
+    def corr_matrix(self, X, theta1, theta2=None):
+        """HX:328-337 corr.matrix(X, theta) / ANI:351-360 corr.matrix(X, theta1, theta2)."""
+        theta = np.atleast_1d(theta1) if theta2 is None else np.array([theta1, theta2], dtype=np.float64)
+        return self.h.corr_matrix(X, theta)
+
+    def corr_matrix_ISO(self, X, theta):
+        """HX:347-356."""
+        return self.h.corr_matrix(X, float(theta))
+
+    def corr_vec(self, x, X, theta1, theta2=None):
+        """ANI:369-377 corr.vec(x, X, theta1, theta2); general theta vector accepted."""
+        theta = np.atleast_1d(theta1) if theta2 is None else np.array([theta1, theta2], dtype=np.float64)
+        return self.h.corr_cross(np.asarray(x, dtype=np.float64).reshape(1, -1), X, theta)[0]
+
+    def corr_vec_ISO(self, x, X, theta):
+        """HX:367-375."""
+        return self.h.corr_cross(np.asarray(x, dtype=np.float64).reshape(1, -1), X, float(theta))[0]
+
+    # ------------------------------------------------------------------ a4 / a5
+    def _row(self, D_train, p, theta1, theta2, lam=None):
+        d = np.asarray(D_train).shape[1]
+        if self.cfg["aniso"]:
+            if lam is None:
+                raise TypeError("the anisotropic script needs lambda")
+            return pack_aniso(p, theta1, theta2, lam)
+        return pack_iso(p, theta1, theta2, d)
+
+    def Mixed_corr_matrix(self, D_train, p, theta1, theta2, lam=None):
+        """HX:408-415 / ANI:399-406 / ADV:414-421 (theta2 plays 'lambda' there)."""
+        return self.h.mixed_corr_matrix(D_train, 2, self._row(D_train, p, theta1, theta2, lam))
+
+    def Mixed_corr_vec(self, x_new, D_train, p, theta1, theta2, lam=None):
+        """HX:425-431 / ANI:416-422."""
+        x = np.asarray(x_new, dtype=np.float64).reshape(1, -1)
+        return self.h.mixed_corr_cross(x, D_train, 2, self._row(D_train, p, theta1, theta2, lam))[0]
+
+    # ------------------------------------------------------------------ a6 / a7
+    def beta_MLE(self, R_Inv, y):
+        """HX:384-388."""
+        return self.h.beta_mle(R_Inv, y)
+
+    def sigma2_MLE(self, R_Inv, y_train, beta):
+        """HX:394-399."""
+        return self.h.sigma2_mle(R_Inv, y_train, beta)
+
+    # ------------------------------------------------------------------ a8
+    def logpost(self, D_train, theta, y, sigma2, theta1_pars=None, theta2_pars=None, want_R_Inv=True):
+        """HX:441-466 (pars passed) / GV:429-454 / ISO:433-457 / ADV:447-471 / ANI:433-467.
+        Returns dict(val, beta, R_Inv[, like]); NaN / None when R is not factorisable."""
+        theta = np.asarray(theta, dtype=np.float64).ravel()
+        if theta.size != self.cfg["npar"]:
+            raise ValueError("%s logpost takes %d transformed parameters" % (self.script, self.cfg["npar"]))
+        pars = None
+        if self.cfg["prior"] == api.PRIOR_INVGAMMA:
+            if theta1_pars is None or theta2_pars is None:
+                raise TypeError("%s logpost needs theta1.pars and theta2.pars" % self.script)
+            pars = np.concatenate([np.ravel(theta1_pars)[:2], np.ravel(theta2_pars)[:2]])
+        r = self.h.logpost(D_train, y, sigma2, self.cfg["prior"], theta, pars, want_Rinv=want_R_Inv)
+        out = dict(val=r["val"], beta=r["beta"], R_Inv=r["R_inv"] if r["status"] == 0 else None)
+        if self.script == "ADV":
+            out["like"] = float(np.exp(r["loglik"]))  # ADV:470
+        return out
+
+    # ------------------------------------------------------------------ a9
+    def likeli_hyperpars(self, D_train, y_train, theta1_pars, theta2_pars, sigma2, aniso_lambda=None):
+        """HX:549-575 / ADV:552-578: mean over the Halton nodes of exp(cond.like)."""
+        hyper = np.array([[theta1_pars[0], theta1_pars[1], theta2_pars[0], theta2_pars[1]]], dtype=np.float64)
+        out, _ = self.h.grid_marginal(D_train, y_train, sigma2, hyper, self.cfg["N"], self.cfg["tau"],
+                                      take_log=False,
+                                      aniso_lambda=-1.0 if aniso_lambda is None else aniso_lambda)
+        return float(out[0])
+
+    def choose_hyperpars(self, D_train, y_train, hyperpars_matrix, sigma2, aniso_lambda=None):
+        """HX:584-595 (log of the mean) / ADV:588-599 (the mean itself).
+        Returns dict(pars = winning row, likelihoods = per-row values)."""
+        hyper = np.asarray(hyperpars_matrix, dtype=np.float64)
+        out, arg = self.h.grid_marginal(D_train, y_train, sigma2, hyper, self.cfg["N"], self.cfg["tau"],
+                                        take_log=self.cfg["take_log"],
+                                        aniso_lambda=-1.0 if aniso_lambda is None else aniso_lambda)
+        return dict(pars=hyper[arg], likelihoods=out, which_max=arg)
+
+    # ------------------------------------------------------------------ a10 / a11
+    def factors(self, MCMC_data, n_train, y_train):
+        """HX:604-613: MCMC.data = (R.Inv flattened column-major, beta) ->
+        c(mean.factor, var.factor1, var.factor2)."""
+        data = np.asarray(MCMC_data, dtype=np.float64).ravel()
+        R_Inv = data[: n_train * n_train].reshape(n_train, n_train, order="F")
+        return self.h.factors(R_Inv, data[n_train * n_train], y_train)
+
+    def predict_post(self, x_new, D_train, pars, sigma2):
+        """HX:655-673 / ANI:604-623 / ADV:660-678: one frame row -> (mean, var).
+        pars = (p, theta1, theta2[, lambda], beta, mean.factor[n], var.factor1[n],
+        var.factor2, R.Inv[n*n])."""
+        D_train = np.asarray(D_train, dtype=np.float64)
+        n = D_train.shape[0]
+        pars = np.asarray(pars, dtype=np.float64).ravel()
+        o = 4 if self.cfg["aniso"] else 3
+        p, theta1, theta2 = pars[0], pars[1], pars[2]
+        beta = pars[o]
+        mf = pars[o + 1: o + 1 + n]
+        v1 = pars[o + 1 + n: o + 1 + 2 * n]
+        v2 = pars[o + 1 + 2 * n]
+        R_Inv = pars[o + 2 + 2 * n: o + 2 + 2 * n + n * n].reshape(n, n, order="F")
+        if self.cfg["aniso"]:
+            r = self.Mixed_corr_vec(x_new, D_train, p, theta1, theta2, pars[3])
+        elif self.script == "ADV":
+            r = self.Mixed_corr_vec(x_new, D_train, p, theta1, theta1 * (1.0 + theta2))  # ADV:672 as written
+        else:
+            r = self.Mixed_corr_vec(x_new, D_train, p, theta1, theta2)
+        mean, var = self.h.predict_from_factors(r.reshape(1, -1), beta, mf, v1, v2, R_Inv, sigma2)
+        return np.array([[mean[0], var[0]]])
+
+    # ------------------------------------------------------------------ batched forms
+    def draws_to_params(self, D_train, draws):
+        """draws rows (p, theta1, theta2[, lambda]) -> C-ABI parameter matrix."""
+        draws = np.atleast_2d(np.asarray(draws, dtype=np.float64))
+        return np.stack([self._row(D_train, *row) for row in draws])
+
+    def prediction_table(self, D_test, draws, D_train, sigma2, y_train):
+        """The deterministic part of prediction()/compare.GP (HX:686-693, HX:713-725): the
+        (draw x test point) mean and variance tables and y.hat = colMeans(mean).  The
+        rnorm/quantile interval step (HX:696-699) needs R's RNG and is out of scope."""
+        params = self.draws_to_params(D_train, draws)
+        mean, var, beta, status = self.h.predict_batch(D_train, y_train, 2, params, D_test, sigma2)
+        return dict(mean=mean, var=var, beta=beta, status=status, y_hat=mean.mean(axis=0))
+
+    def factors_frame_from_draws(self, draws, D_train, sigma2, y_train):
+        """Materialise the data frame factors.frame() returns (HX:625-644) for drop-in
+        callers, given the posterior draws (the Metropolis chain itself is out of scope):
+        columns p, theta1, theta2[, lambda], beta, mean.factor, var.factor1, var.factor2, R.Inv."""
+        D_train = np.asarray(D_train, dtype=np.float64)
+        n = D_train.shape[0]
+        draws = np.atleast_2d(np.asarray(draws, dtype=np.float64))
+        rows = []
+        for row in draws:
+            p, t1, t2 = row[0], row[1], row[2]
+            theta_t = [np.log(t1), np.log(t2), np.log(p / (1.0 - p))]
+            if self.cfg["aniso"]:
+                theta_t.append(np.log(row[3]))
+            pars = (1.0, 1.0, 1.0, 1.0)
+            lp = self.h.logpost(D_train, y_train, sigma2, self.cfg["prior"], np.array(theta_t), pars)
+            f = self.h.factors(lp["R_inv"], lp["beta"], y_train)
+            rows.append(np.concatenate([row, [lp["beta"]], f, lp["R_inv"].ravel(order="F")]))
+        return np.stack(rows)

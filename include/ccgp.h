@@ -1,0 +1,187 @@
+/*
+ * libccgp -- C ABI of the MI355X-native Combined-GP evaluation path.
+ *
+ * The reference (oharari/Convex-Combination-of-Gaussian-Processes) has no FFI: its
+ * "API" is a set of global R functions.  Each entry point below replaces the
+ * arithmetic of one or more of those functions; the R-side .Call() stub that binds
+ * it is in r/ccgp_shim.c and shown in INTEGRATION.md.  Reference abbreviations:
+ *   HX  = Heat Exchanger Emulator/Combined GP Heat Exchanger.R
+ *   ANI = 2D Codes and Designs/2D Combined GP Anisotropic Public.R
+ *   ADV = 2D Codes and Designs/2D Combined GP Isotropic Advanced.R
+ *   GV  = Ground Vibrations Emulator/Combined GP Ground Vibrations.R
+ *
+ * Conventions
+ *   - every matrix is fp64, COLUMN-MAJOR (R's native layout), no padding:
+ *     X is n x d (X[i + k*n]); a parameter matrix with B draws is B x P
+ *     (params[b + j*B]).
+ *   - one draw of K component GPs in d dimensions is the row
+ *        ( w_1..w_K , theta_{1,1..d} , ... , theta_{K,1..d} ),   P = K + K*d,
+ *     and means  Sigma = sigma2 * sum_c w_c^2 R_c(theta_c),
+ *                R_c[i,j] = exp(-sum_k theta_ck (x_ik - x_jk)^2).
+ *     The reference's (p, theta1, theta2) isotropic draw (HX:408-415) is
+ *     w = (p, 1-p), theta_1k = theta1, theta_2k = theta2; its anisotropic draw
+ *     (ANI:399-406) is theta_1 = (theta1,theta2), theta_2 = (1+lambda)(theta1,theta2).
+ *   - the caller owns every buffer; the library allocates only device scratch kept
+ *     in the handle.  A handle is bound to ONE HIP device and is not re-entrant
+ *     (R is single-threaded; one handle per host thread / per GPU process).
+ *   - return value: 0 ok, <0 error (ccgp_last_error), >0 = number of evaluations in
+ *     the batch whose factorisation met a non-positive pivot.  Per-evaluation
+ *     status[b] = 0 or 1-based index of the first bad pivot; such an evaluation
+ *     returns NaN -- the reference's NA from try(solve(R)) (HX:454-455).
+ *   - "_dev" entry points take DEVICE pointers and only enqueue work on the
+ *     handle's stream (no allocation, no synchronisation once the workspace has
+ *     been sized by ccgp_reserve); the others take HOST pointers and block.
+ */
+#ifndef CCGP_H
+#define CCGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ccgp_handle ccgp_handle;
+
+enum {
+  CCGP_OK = 0,
+  CCGP_EINVAL = -1,       /* bad argument */
+  CCGP_EHIP = -2,         /* a HIP runtime call failed */
+  CCGP_ENOMEM = -3,       /* device workspace allocation failed */
+  CCGP_EUNSUPPORTED = -4  /* combination not implemented (message says which) */
+};
+
+/* how the mean and the extra variance enter the likelihood */
+enum {
+  CCGP_MEAN_PROFILE_BETA = 0,  /* logpost: beta = 1'R^-1 y / 1'R^-1 1  (HX:458-460)        */
+  CCGP_MEAN_ZERO_PLUS_TAU2 = 1 /* cond.like: mean 0, Sigma + tau^2 11'    (HX:567-570)        */
+};
+
+/* which script's log-prior ccgp_logpost adds */
+enum {
+  CCGP_PRIOR_INVGAMMA = 0, /* HX:462 / ADV:467, pars (a1,b1,a2,b2)                          */
+  CCGP_PRIOR_GV = 1,       /* GV:450                                                        */
+  CCGP_PRIOR_ISO = 2,      /* ISO:453 = BSQ:450 = D1:636                                    */
+  CCGP_PRIOR_ANI = 3       /* ANI:462 (4 transformed parameters, anisotropic kernel)        */
+};
+
+/* ---- lifetime --------------------------------------------------------------------- */
+int ccgp_create(int device, ccgp_handle** out);
+int ccgp_destroy(ccgp_handle* h);
+const char* ccgp_last_error(const ccgp_handle* h);
+const char* ccgp_version(void);
+/* run on a caller-owned hipStream_t (pass NULL to go back to the handle's own stream) */
+int ccgp_set_stream(ccgp_handle* h, void* hip_stream);
+/* cap on device scratch used per launch group (default 24 GiB); batches are chunked */
+int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
+/* pre-size scratch so that later _dev calls of this shape never allocate */
+int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);
+int ccgp_synchronize(ccgp_handle* h);
+
+/* ---- a1/a2/a3: covariance kernels ---------------------------------------------------
+ * corr.matrix(X, theta) HX:328-337 / ANI:351-360, corr.matrix.ISO HX:347-356 (caller
+ * replicates theta d times); corr.vec / corr.vec.ISO HX:367-375, ANI:369-377 are the
+ * m = 1 case of ccgp_corr_cross.  out_R is n x n, out is m x n (row t = r(x_t)). */
+int ccgp_corr_matrix(ccgp_handle* h, const double* X, int n, int d, const double* theta,
+                     double* out_R);
+int ccgp_corr_cross(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d,
+                    const double* theta, double* out);
+
+/* ---- a4/a5: convex-combination mix ---------------------------------------------------
+ * Mixed.corr.matrix HX:408-415, ANI:399-406, ADV:414-421; Mixed.corr.vec HX:425-431,
+ * ANI:416-422.  params is ONE row (P doubles). */
+int ccgp_mixed_corr_matrix(ccgp_handle* h, const double* X, int n, int d, int K,
+                           const double* params, double* out_R);
+int ccgp_mixed_corr_cross(ccgp_handle* h, const double* Xnew, int m, const double* X, int n,
+                          int d, int K, const double* params, double* out);
+
+/* ---- a6/a7: beta.MLE HX:384-388, sigma2.MLE HX:394-399 (explicit R.Inv given) -------- */
+int ccgp_beta_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double* out_beta);
+int ccgp_sigma2_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double beta,
+                    double* out_sigma2);
+
+/* ---- a8/a9/a12: batched log-likelihood ----------------------------------------------
+ * For each of B draws: build the mixed covariance, factorise, solve, return
+ *   mode 0: dmnorm(y, beta_hat, sigma2*sum(w^2)*R_mixed, log)   (HX:454-460), out_beta
+ *   mode 1: dmnorm(y, 0, sigma2*sum(w^2)*R_mixed + tau2 11', log) (HX:567-570), beta = 0
+ * out_beta / status may be NULL. */
+int ccgp_loglik_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                      const double* params, int B, double sigma2, int mean_mode, double tau2,
+                      double* out_loglik, double* out_beta, int* status);
+int ccgp_loglik_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy, int K,
+                          const double* dparams, int B, double sigma2, int mean_mode, double tau2,
+                          double* d_loglik, double* d_beta, int* d_status);
+
+/* build-defined extension (the reference has no analytic gradient; LearnBayes::laplace
+ * differences numerically, HX:493): d loglik(mode 0, beta profiled) / d params[b, j],
+ * out_grad is B x P column-major. */
+int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                           const double* params, int B, double sigma2, double* out_loglik,
+                           double* out_beta, double* out_grad, int* status);
+
+/* ---- a8 (+a13): logpost(D.train, theta, y, sigma2[, pars]) -> list(val, beta, R.Inv) --
+ * theta_t = (psi1, psi2, phi[, zeta]) on the transformed scale; prior_pars =
+ * (a1,b1,a2,b2) for CCGP_PRIOR_INVGAMMA, ignored otherwise.  out_loglik (the bare
+ * dmnorm term; ADV:470 returns its exp) and out_Rinv (n x n, solve(R) of HX:454) may be
+ * NULL. *status as in the batch call. */
+int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2,
+                 int prior_id, const double* theta_t, const double* prior_pars, double* out_val,
+                 double* out_beta, double* out_loglik, double* out_Rinv, int* status);
+
+/* ---- a9: likeli.hyperpars HX:549-575 / choose.hyperpars HX:584-595, ADV:552-599 -------
+ * hyper is G x 4 (alpha1 beta1 alpha2 beta2).  For each row: N base-2 Halton quantiles
+ * u_j, p = u_j, theta1 = qigamma(u_j, a1, b1), theta2 = qigamma(u_j, a2, b2), mode-1
+ * likelihood with tau2 = tau^2, mean of exp() over j (accumulated as log-sum-exp).
+ * out[g] = log(mean) if take_log (HX:591) else mean (ADV:595); *out_argmax is the
+ * 0-based which.max row.  aniso_lambda < 0: isotropic kernel (HX/ADV); >= 0: the
+ * anisotropic kernel of ANI:399-406 with d = 2, (theta1,theta2) per dimension and that
+ * fixed lambda (BASELINE config 3).  out_logs (G x N, may be NULL) receives every
+ * conditional log-likelihood. */
+int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const double* y,
+                       double sigma2, const double* hyper, int G, int N, double tau, int take_log,
+                       double aniso_lambda, double* out, int* out_argmax, double* out_logs);
+/* the quadrature nodes the call above uses, exposed for the R surface / tests */
+int ccgp_halton_base2(int N, double* out);
+int ccgp_qigamma(const double* p, int N, double alpha, double beta, double* out);
+
+/* ---- a10/a11: factors HX:604-613, predict.post HX:655-673 / ANI:604-623 --------------
+ * ccgp_predict_batch recomputes, per draw, what Metro caches (R.Inv, beta; HX:515-525)
+ * and returns the S x m tables mean[s + t*S], var[s + t*S] that prediction() averages
+ * (HX:688-693).  out_beta (S) and status (S) may be NULL. */
+int ccgp_predict_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                       const double* params, int S, const double* Xtest, int m, double sigma2,
+                       double* out_mean, double* out_var, double* out_beta, int* status);
+int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy, int K,
+                           const double* dparams, int S, const double* dXtest, int m,
+                           double sigma2, double* d_mean, double* d_var, double* d_beta,
+                           int* d_status);
+/* literal factors(): out = (mean.factor[n], var.factor1[n], var.factor2) */
+int ccgp_factors(ccgp_handle* h, const double* R_inv, double beta, const double* y, int n,
+                 double* out);
+/* literal predict.post arithmetic with caller-supplied cached terms (HX:667-670);
+ * r is m x n as produced by ccgp_mixed_corr_cross; out_mean/out_var length m. */
+int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, double beta,
+                              const double* mean_factor, const double* var_factor1,
+                              double var_factor2, const double* R_inv, double sigma2,
+                              double* out_mean, double* out_var);
+
+/* ---- measurement hooks (bench.py / rocprof; not part of the R surface) ---------------
+ * Time, with HIP events on the handle's stream, every launch group of the most recent
+ * *_dev call: ids below.  Returns milliseconds summed over launches and the count. */
+enum {
+  CCGP_T_COV = 0,      /* covariance / mix build            */
+  CCGP_T_UPDATE = 1,   /* blocked Cholesky panel update (MFMA) */
+  CCGP_T_DIAG = 2,     /* diagonal-block factor + inverse   */
+  CCGP_T_TRSM = 3,     /* panel triangular solve (MFMA)     */
+  CCGP_T_SOLVE = 4,    /* forward solves + reductions       */
+  CCGP_T_FUSED = 5,    /* small-n fused in-LDS evaluator    */
+  CCGP_T_COUNT = 6
+};
+int ccgp_enable_timing(ccgp_handle* h, int on);
+int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCGP_H */

@@ -1,0 +1,398 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed fixtures.
+
+Tolerances (fp64 throughout): BASELINE.json's north_star asks for rtol 1e-8 on the Qian
+predictions; likelihood terms are held to 1e-9 or tighter except where the covariance is
+itself ill-conditioned (14-point designs under smooth kernels, tau^2 11' added), where
+fp64 -- in R as here -- only delivers cond * eps and the tolerance says so.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import golden, load_gv, load_hyper, load_maximin, load_qian, synthetic_design
+from oracle import ccgp_oracle as orc
+from oracle import mp_check
+
+pytestmark = pytest.mark.gpu
+
+
+def digest_close(M, dig, rtol):
+    scale = dig["fro"]
+    assert float(M.sum()) == pytest.approx(dig["sum"], rel=rtol, abs=rtol * scale)
+    assert float(np.trace(M)) == pytest.approx(dig["trace"], rel=rtol, abs=rtol * scale)
+    assert float(np.linalg.norm(M)) == pytest.approx(dig["fro"], rel=rtol)
+    for i, j, v in dig["entries"]:
+        assert M[i, j] == pytest.approx(v, rel=rtol, abs=rtol * scale / M.shape[0])
+
+
+def rand_iso_draws(rng, B, d):
+    return np.stack([orc.params_from_iso(rng.uniform(0.55, 0.95), rng.uniform(0.1, 1.5), rng.uniform(8, 60), d)
+                     for _ in range(B)])
+
+
+# ------------------------------------------------------------------------------- a1-a5
+def test_corr_kernels_qian(handle):
+    from ccgp_amd.rsurface import CombinedGP
+    gp = CombinedGP("HX", handle=handle)
+    D, y, Dt, _ = load_qian()
+    g = golden("hx_golden.json")
+    th = g["corr_matrix_general"]["theta"]
+    R = gp.corr_matrix(D, th)
+    np.testing.assert_allclose(R, orc.corr_matrix(D, th), rtol=1e-13, atol=1e-15)
+    digest_close(R, g["corr_matrix_general"]["R"], 1e-12)
+    np.testing.assert_allclose(gp.corr_matrix_ISO(D, 0.45), orc.corr_matrix_iso(D, 0.45), rtol=1e-13)
+    cv = g["corr_vec_iso"]
+    np.testing.assert_allclose(gp.corr_vec_ISO(cv["x"], D, cv["theta"]), cv["r"], rtol=1e-12)
+    np.testing.assert_allclose(gp.Mixed_corr_matrix(D, 0.8, 0.3, 15.0), orc.mixed_corr_matrix_iso(D, 0.8, 0.3, 15.0),
+                               rtol=1e-13)
+    np.testing.assert_allclose(gp.Mixed_corr_vec(Dt[3], D, 0.8, 0.3, 15.0),
+                               orc.mixed_corr_vec_iso(Dt[3], D, 0.8, 0.3, 15.0), rtol=1e-12)
+    # cross matrix with m > 64 and n not a multiple of 64 (ragged tiles)
+    Dg, _, Dtg, _ = load_gv(90)
+    C = handle.corr_cross(Dtg, Dg, 0.3)
+    want = np.stack([orc.corr_vec_iso(x, Dg, 0.3) for x in Dtg])
+    np.testing.assert_allclose(C, want, rtol=1e-12)
+
+
+def test_corr_kernels_aniso(handle):
+    from ccgp_amd.rsurface import CombinedGP
+    gp = CombinedGP("ANI", handle=handle)
+    D = load_maximin(100)
+    np.testing.assert_allclose(gp.corr_matrix(D, 0.8, 1.5), orc.corr_matrix(D, [0.8, 1.5]), rtol=1e-13)
+    np.testing.assert_allclose(gp.Mixed_corr_matrix(D, 0.7, 0.8, 1.5, 6.0),
+                               orc.mixed_corr_matrix_aniso(D, 0.7, 0.8, 1.5, 6.0), rtol=1e-13)
+    np.testing.assert_allclose(gp.corr_vec([0.1, -0.4], D, 0.8, 1.5), orc.corr_vec([0.1, -0.4], D, [0.8, 1.5]), rtol=1e-12)
+    np.testing.assert_allclose(gp.Mixed_corr_vec([0.1, -0.4], D, 0.7, 0.8, 1.5, 6.0),
+                               orc.mixed_corr_vec_aniso([0.1, -0.4], D, 0.7, 0.8, 1.5, 6.0), rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------- a6, a7, a10, a11 literal forms
+def test_rinv_helpers_and_literal_predict_post(handle):
+    from ccgp_amd.rsurface import CombinedGP
+    gp = CombinedGP("HX", handle=handle)
+    D, y, Dt, _ = load_qian()
+    s2 = 10.0
+    R_inv = orc.solve_inverse(orc.mixed_corr_matrix_iso(D, 0.8, 0.3, 15.0))
+    beta = orc.beta_mle(R_inv, y)
+    assert gp.beta_MLE(R_inv, y) == pytest.approx(beta, rel=1e-11)
+    assert gp.sigma2_MLE(R_inv, y, beta) == pytest.approx(orc.sigma2_mle(R_inv, y, beta), rel=1e-9)
+    mf, v1, v2 = orc.factors(R_inv, beta, y)
+    f = gp.factors(np.concatenate([R_inv.ravel(order="F"), [beta]]), 64, y)
+    np.testing.assert_allclose(f[:64], mf, rtol=1e-9, atol=1e-9 * np.abs(mf).max())
+    np.testing.assert_allclose(f[64:128], v1, rtol=1e-9, atol=1e-9 * np.abs(v1).max())
+    assert f[128] == pytest.approx(v2, rel=1e-9)
+    pars = np.concatenate([[0.8, 0.3, 15.0, beta], mf, v1, [v2], R_inv.ravel(order="F")])
+    for j in (0, 5, 13):
+        got = gp.predict_post(Dt[j], D, pars, s2)
+        want = orc.predict_post_iso(Dt[j], D, y, 0.8, 0.3, 15.0, s2)
+        assert got[0, 0] == pytest.approx(want[0], rel=1e-10)
+        assert got[0, 1] == pytest.approx(want[1], rel=1e-8, abs=1e-10 * s2)
+
+
+# ------------------------------------------------------------------------------- a8 / a12, small path
+@pytest.mark.parametrize("mode", [0, 1])
+def test_loglik_batch_qian_vs_oracle(handle, mode):
+    D, y, _, _ = load_qian()
+    s2 = float(np.var(y, ddof=1))
+    rng = np.random.default_rng(11)
+    P = rand_iso_draws(rng, 24, 4)
+    ll, beta, st = handle.loglik_batch(D, y, 2, P, s2, mode, 2500.0)
+    assert not st.any()
+    for b in range(P.shape[0]):
+        w, Th = orc.unpack_params(P[b], 2, 4)
+        wl, wb = orc.loglik_general(D, y, w, Th, s2, mode, 2500.0)
+        assert ll[b] == pytest.approx(wl, rel=1e-10)
+        assert beta[b] == pytest.approx(wb, rel=1e-10, abs=1e-13)
+
+
+def test_logpost_golden_every_script(handle):
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, _, _ = load_qian()
+    g = golden("hx_golden.json")
+    gp = CombinedGP("HX", handle=handle)
+    for c in g["cases"]:
+        r = gp.logpost(D, c["theta_t"], y, c["sigma2"], g["theta1_pars"], g["theta2_pars"])
+        assert r["val"] == pytest.approx(c["val"], rel=1e-10)
+        assert r["beta"] == pytest.approx(c["beta"], rel=1e-10)
+        digest_close(r["R_Inv"], c["R_inv"], 1e-8)
+
+    ga = golden("ani_golden.json")
+    D100, y100 = load_maximin(100), np.array(ga["y"])
+    gpa = CombinedGP("ANI", handle=handle)
+    for c in ga["cases"]:
+        r = gpa.logpost(D100, c["theta_t"], y100, c["sigma2"])
+        # 100 points under these smooth draws: cond(R) = 4e5 .. 1.4e8
+        assert r["val"] == pytest.approx(c["val"], rel=1e-7)
+        assert r["beta"] == pytest.approx(c["beta"], rel=1e-6, abs=1e-9)
+        digest_close(r["R_Inv"], c["R_inv"], 1e-5)
+
+    gv = golden("gv_golden.json")
+    gpg = CombinedGP("GV", handle=handle)
+    for s in gv["sets"]:
+        Dg, yg, _, _ = load_gv(s["size"])
+        for c in s["cases"]:
+            r = gpg.logpost(Dg, c["theta_t"], yg, s["sigma2"])
+            assert r["val"] == pytest.approx(c["val"], rel=1e-10)
+            assert r["beta"] == pytest.approx(c["beta"], rel=1e-9, abs=1e-12)
+            digest_close(r["R_Inv"], c["R_inv"], 1e-8)
+
+    gd = golden("adv_golden.json")
+    D14, y14 = load_maximin(14), np.array(gd["y"])
+    gpd = CombinedGP("ADV", handle=handle)
+    for c in gd["cases"]:
+        r = gpd.logpost(D14, c["theta_t"], y14, gd["sigma2"], c["prior_pars"][:2], c["prior_pars"][2:])
+        # 14 smooth points: cond(R) ~ 1e8..1e11, so only cond*eps can be asked for
+        assert r["val"] == pytest.approx(c["val"], rel=1e-6)
+        assert r["like"] == pytest.approx(c["like"], rel=1e-4)
+
+    # ISO / BSQ share one prior (ISO:453 = BSQ:450)
+    t = [0.1, 2.5, 0.9]
+    for script in ("ISO", "BSQ"):
+        r = CombinedGP(script, handle=handle).logpost(D, t, y, 10.0)
+        assert r["val"] == pytest.approx(orc.logpost(D, t, y, 10.0, script)["val"], rel=1e-10)
+
+
+# ------------------------------------------------------------------------------- a9
+def test_hx_grid_full_624_rows(handle):
+    """BASELINE config 2: 624 rows x 1000 Halton nodes on the Qian design (HX:584-595)."""
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, _, _ = load_qian()
+    g = golden("hx_golden.json")["grid"]
+    H = load_hyper("hx")
+    vals, arg, logs = handle.grid_marginal(D, y, g["sigma2"], H, g["N"], g["tau"], g["take_log"], want_logs=True)
+    np.testing.assert_allclose(logs[0], g["row0_logs"], rtol=1e-9)
+    np.testing.assert_allclose(vals, g["values"], rtol=1e-9)
+    assert arg == g["which_max"]
+    r = CombinedGP("HX", handle=handle).choose_hyperpars(D, y, H[:16], g["sigma2"])
+    np.testing.assert_allclose(r["likelihoods"], g["values"][:16], rtol=1e-9)
+    np.testing.assert_array_equal(r["pars"], H[int(np.argmax(g["values"][:16]))])
+    one = CombinedGP("HX", handle=handle).likeli_hyperpars(D, y, H[7, :2], H[7, 2:], g["sigma2"])
+    assert math.log(one) == pytest.approx(g["values"][7], rel=1e-9)
+
+
+def test_config3_aniso_grid(handle):
+    """BASELINE config 3: 60 x 1728 grid on maximin-100 with the anisotropic kernel."""
+    ga = golden("ani_golden.json")
+    g = ga["grid"]
+    D, y = load_maximin(100), np.array(ga["y"])
+    # scale columns x16: as bundled (tuned for 14 points) cond(Sigma) reaches 7e15 on this design
+    H = load_hyper("adv") * np.array([1.0, g["b_scale"], 1.0, g["b_scale"]])
+    vals, arg, logs = handle.grid_marginal(D, y, g["sigma2"], H, g["N"], g["tau"], g["take_log"],
+                                           aniso_lambda=g["aniso_lambda"], want_logs=True)
+    np.testing.assert_allclose(logs[0], g["row0_logs"], rtol=1e-8, atol=1e-7)     # cond <= ~1e8
+    np.testing.assert_allclose(vals, g["values"], rtol=1e-6)
+    assert arg == g["which_max"]
+
+
+def test_adv_grid(handle):
+    from ccgp_amd.rsurface import CombinedGP
+    gd = golden("adv_golden.json")
+    D14, y14 = load_maximin(14), np.array(gd["y"])
+    H = load_hyper("adv")
+    r = CombinedGP("ADV", handle=handle).choose_hyperpars(D14, y14, H, gd["sigma2"])
+    np.testing.assert_allclose(r["likelihoods"], gd["grid"]["values"], rtol=1e-4)
+    assert r["which_max"] == gd["grid"]["which_max"]
+    # arbitrate two nodes at 50 digits: the HIP value must be within cond*eps of the truth
+    u = orc.runif_halton(4)
+    for j in (0, 3):
+        th1, th2 = orc.qigamma(u[j], H[5, 0], H[5, 1]), orc.qigamma(u[j], H[5, 2], H[5, 3])
+        row = orc.params_from_iso(u[j], float(th1), float(th2), 2)
+        w, Th = orc.unpack_params(row, 2, 2)
+        got, _, _ = handle.loglik_batch(D14, y14, 2, row[None], gd["sigma2"], 1, 100.0 ** 2)
+        S = gd["sigma2"] * np.sum(w ** 2) * orc.mixed_corr_matrix_general(D14, w, Th) + 100.0 ** 2
+        tol = 50 * np.linalg.cond(S) * np.finfo(float).eps
+        truth = float(mp_check.loglik(D14, y14, w, Th, gd["sigma2"], 1, 100.0 ** 2)[0])
+        assert abs(got[0] - truth) <= tol * abs(truth) + 1e-9
+
+
+# ------------------------------------------------------------------------------- a10 + a11 batched
+def test_qian_predictions_rtol_1e8(handle):
+    """north_star: predictions match the reference math to rtol 1e-8 on the Qian set."""
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, Dt, _ = load_qian()
+    g = golden("hx_golden.json")
+    t = CombinedGP("HX", handle=handle).prediction_table(Dt, g["draws"], D, g["predict"]["sigma2"], y)
+    assert not t["status"].any()
+    np.testing.assert_allclose(t["mean"], g["predict"]["mean"], rtol=1e-8)
+    np.testing.assert_allclose(t["var"], g["predict"]["var"], rtol=1e-8)
+    np.testing.assert_allclose(t["beta"], g["predict"]["beta"], rtol=1e-8)
+    np.testing.assert_allclose(t["y_hat"], np.mean(g["predict"]["mean"], axis=0), rtol=1e-8)
+
+
+def test_ground_vibrations_prediction_tables(handle):
+    """BASELINE config 5 shapes: n = 50 / 90, d = 9, m = 150 / 110 (chunked test points)."""
+    from ccgp_amd.rsurface import CombinedGP
+    gv = golden("gv_golden.json")
+    gp = CombinedGP("GV", handle=handle)
+    for s in gv["sets"]:
+        Dg, yg, Dtg, _ = load_gv(s["size"])
+        t = gp.prediction_table(Dtg, s["draws"], Dg, s["sigma2"], yg)
+        np.testing.assert_allclose(t["mean"], s["mean"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(t["var"], s["var"], rtol=1e-8, atol=1e-10 * s["sigma2"])
+        np.testing.assert_allclose(t["beta"], s["beta"], rtol=1e-8, atol=1e-11)
+
+
+def test_aniso_prediction_table(handle):
+    from ccgp_amd.rsurface import CombinedGP
+    ga = golden("ani_golden.json")
+    D, y = load_maximin(100), np.array(ga["y"])
+    t = CombinedGP("ANI", handle=handle).prediction_table(np.array(ga["Xtest"]), ga["draws"], D,
+                                                         ga["predict"]["sigma2"], y)
+    # cond(R) up to 1.4e8 for these draws (see test_logpost_golden_every_script)
+    np.testing.assert_allclose(t["mean"], ga["predict"]["mean"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(t["var"], ga["predict"]["var"], rtol=1e-5, atol=1e-7 * ga["predict"]["sigma2"])
+
+
+def test_factors_frame_converter(handle):
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, Dt, _ = load_qian()
+    gp = CombinedGP("HX", handle=handle)
+    frame = gp.factors_frame_from_draws([(0.8, 0.3, 15.0), (0.7, 0.5, 25.0)], D, 10.0, y)
+    assert frame.shape == (2, 5 + 2 * 64 + 64 * 64)            # HX:631-643 row width
+    got = gp.predict_post(Dt[2], D, frame[1], 10.0)
+    want = orc.predict_post_iso(Dt[2], D, y, 0.7, 0.5, 25.0, 10.0)
+    assert got[0, 0] == pytest.approx(want[0], rel=1e-9) and got[0, 1] == pytest.approx(want[1], rel=1e-7)
+
+
+# ------------------------------------------------------------------------------- blocked path (n > 128)
+@pytest.mark.parametrize("n,d,K", [(129, 3, 2), (200, 5, 3), (256, 5, 3), (640, 5, 3), (1000, 4, 2)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_blocked_path_vs_oracle(handle, n, d, K, mode):
+    X, y = synthetic_design(n, d, seed=n)
+    rng = np.random.default_rng(n + mode)
+    B = 5
+    P = np.empty((B, K + K * d))
+    for b in range(B):
+        w = rng.dirichlet(np.ones(K))
+        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
+        th[-1] = np.maximum(th[-1], 40.0)     # the rough component keeps R numerically PD
+        P[b] = np.concatenate([w, th.ravel()])
+    ll, beta, st = handle.loglik_batch(X, y, K, P, 1.3, mode, 9.0)
+    assert not st.any()
+    for b in range(B):
+        w, Th = orc.unpack_params(P[b], K, d)
+        wl, wb = orc.loglik_general(X, y, w, Th, 1.3, mode, 9.0)
+        assert ll[b] == pytest.approx(wl, rel=1e-9)
+        assert beta[b] == pytest.approx(wb, rel=1e-8, abs=1e-11)
+
+
+def test_small_and_blocked_agree_across_the_cutover(handle):
+    """n = 128 runs the fused kernel, n = 129 the blocked one: appending one far-away,
+    nearly independent point must change the likelihood by exactly its own marginal term."""
+    X, y = synthetic_design(129, 2, seed=5)
+    P = orc.params_from_iso(0.7, 30.0, 200.0, 2)[None]
+    a, _, _ = handle.loglik_batch(X[:128], y[:128], 2, P, 1.0, 1, 4.0)
+    b, _, _ = handle.loglik_batch(X, y, 2, P, 1.0, 1, 4.0)
+    w, Th = orc.unpack_params(P[0], 2, 2)
+    assert a[0] == pytest.approx(orc.loglik_general(X[:128], y[:128], w, Th, 1.0, 1, 4.0)[0], rel=1e-10)
+    assert b[0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.0, 1, 4.0)[0], rel=1e-10)
+
+
+def test_n4096_against_lapack_and_invariances(handle):
+    """BASELINE config 4 size.  One direct LAPACK comparison (seconds on CPU) plus
+    size-independent properties: determinism, batch-position independence, invariance of the
+    likelihood under a permutation of the design rows."""
+    n, d, K = 4096, 5, 3
+    X, y = synthetic_design(n, d, seed=20140101)
+    rng = np.random.default_rng(7)
+    B = 8
+    P = np.empty((B, K + K * d))
+    for b in range(B):
+        w = rng.dirichlet(np.ones(K))
+        th = np.exp(rng.uniform(np.log(0.5), np.log(50.0), size=(K, d)))
+        th[-1] = np.maximum(th[-1], 20.0)
+        P[b] = np.concatenate([w, th.ravel()])
+    P[5] = P[2]                                   # same draw at two batch positions
+    ll, beta, st = handle.loglik_batch(X, y, K, P, 1.0, 0, 0.0)
+    assert not st.any() and np.all(np.isfinite(ll))
+    assert ll[5] == ll[2] and beta[5] == beta[2]
+    ll2, beta2, _ = handle.loglik_batch(X, y, K, P, 1.0, 0, 0.0)
+    np.testing.assert_array_equal(ll, ll2)        # deterministic
+    perm = np.random.default_rng(1).permutation(n)
+    llp, betap, _ = handle.loglik_batch(X[perm], y[perm], K, P[:2], 1.0, 0, 0.0)
+    np.testing.assert_allclose(llp, ll[:2], rtol=1e-9)
+    np.testing.assert_allclose(betap, beta[:2], rtol=1e-7, atol=1e-10)
+    # direct check of one draw with LAPACK Cholesky (not the LU inverse: seconds, not minutes)
+    import scipy.linalg as sla
+    w, Th = orc.unpack_params(P[0], K, d)
+    R = orc.mixed_corr_matrix_general(X, w, Th)
+    L = sla.cholesky(R, lower=True)
+    zy = sla.solve_triangular(L, y, lower=True)
+    z1 = sla.solve_triangular(L, np.ones(n), lower=True)
+    b0 = (z1 @ zy) / (z1 @ z1)
+    c = 1.0 * np.sum(w ** 2)
+    want = -0.5 * (n * math.log(2 * math.pi) + n * math.log(c) + 2 * np.log(np.diag(L)).sum()
+                   + np.sum((zy - b0 * z1) ** 2) / c)
+    assert ll[0] == pytest.approx(want, rel=1e-9)
+    assert beta[0] == pytest.approx(b0, rel=1e-7, abs=1e-10)
+
+
+# ------------------------------------------------------------------------------- failure detection
+def test_non_positive_definite_maps_to_na(handle):
+    """HX:454-455: a singular R gives NA, not an abort.  A duplicated design point makes R
+    exactly singular; status carries the 1-based pivot and the value is NaN."""
+    D, y, _, _ = load_qian()
+    Dd = D.copy()
+    Dd[40] = Dd[3]
+    P = np.stack([orc.params_from_iso(0.8, 0.3, 15.0, 4), orc.params_from_iso(0.7, 0.5, 25.0, 4)])
+    ll, beta, st = handle.loglik_batch(Dd, y, 2, P, 10.0, 0, 0.0)
+    assert np.all(st > 0) and np.all(st <= 64) and np.all(np.isnan(ll)) and np.all(np.isnan(beta))
+    ok, _, st_ok = handle.loglik_batch(D, y, 2, P, 10.0, 0, 0.0)
+    assert not st_ok.any() and np.all(np.isfinite(ok))
+    from ccgp_amd.rsurface import CombinedGP
+    r = CombinedGP("GV", handle=handle).logpost(Dd, [0.0, 2.0, 1.0], y, 10.0)
+    assert math.isnan(r["val"]) and r["R_Inv"] is None
+    # blocked path
+    X, yy = synthetic_design(300, 3, seed=9)
+    X[250] = X[17]
+    Pb = orc.params_from_iso(0.6, 2.0, 9.0, 3)[None]
+    llb, _, stb = handle.loglik_batch(X, yy, 2, Pb, 1.0, 0, 0.0)
+    assert stb[0] > 0 and math.isnan(llb[0])
+
+
+def test_edge_shapes(handle):
+    D, y, Dt, _ = load_qian()
+    ll, beta, st = handle.loglik_batch(D, y, 2, np.empty((0, 10)), 1.0)
+    assert ll.shape == (0,)
+    # n = 1 and n = 2
+    for n in (1, 2, 3):
+        P = orc.params_from_iso(0.8, 0.3, 15.0, 4)[None]
+        w, Th = orc.unpack_params(P[0], 2, 4)
+        got, gb, _ = handle.loglik_batch(D[:n], y[:n], 2, P, 2.0, 1, 9.0)
+        assert got[0] == pytest.approx(orc.loglik_general(D[:n], y[:n], w, Th, 2.0, 1, 9.0)[0], rel=1e-12)
+    # single test point, single draw
+    from ccgp_amd.rsurface import CombinedGP
+    t = CombinedGP("HX", handle=handle).prediction_table(Dt[:1], [(0.8, 0.3, 15.0)], D, 10.0, y)
+    m, v = orc.predict_post_iso(Dt[0], D, y, 0.8, 0.3, 15.0, 10.0)
+    assert t["mean"][0, 0] == pytest.approx(m, rel=1e-9) and t["var"][0, 0] == pytest.approx(v, rel=1e-8)
+    # argument errors come back as codes, not crashes
+    from ccgp_amd import api
+    with pytest.raises(api.CcgpError):
+        handle.loglik_batch(D, y, 9, np.ones((1, 45)), 1.0)
+
+
+# ------------------------------------------------------------------------------- gradient extension
+@pytest.mark.parametrize("case", ["maximin14", "qian", "gv90"])
+def test_gradient_matches_finite_differences(handle, case):
+    if case == "maximin14":
+        X = load_maximin(14)
+        y = np.array([orc.test_function_2d(a, b, 3) for a, b in X])
+        rows = np.stack([orc.params_from_aniso(0.7, 2.0, 3.0, 4.0), np.array([0.6, 0.4, 3.0, 5.0, 20.0, 30.0])])
+        K, s2, tol = 2, 0.4, 2e-4
+    elif case == "qian":
+        X, y, _, _ = load_qian()
+        rows = np.stack([orc.params_from_iso(0.8, 0.3, 15.0, 4), orc.params_from_iso(0.7, 0.5, 25.0, 4)])
+        K, s2, tol = 2, 10.0, 1e-5
+    else:
+        X, y, _, _ = load_gv(90)
+        rows = orc.params_from_iso(0.7, 0.3, 15.0, 9)[None]
+        K, s2, tol = 2, float(np.var(y, ddof=1)), 1e-5
+    d = X.shape[1]
+    ll, beta, grad, st = handle.loglik_grad_batch(X, y, K, rows, s2)
+    assert not st.any()
+    for b in range(rows.shape[0]):
+        w, Th = orc.unpack_params(rows[b], K, d)
+        assert ll[b] == pytest.approx(orc.loglik_general(X, y, w, Th, s2)[0], rel=1e-9)
+        fd = orc.loglik_grad_fd(X, y, rows[b], K, d, s2)
+        np.testing.assert_allclose(grad[b], fd, rtol=tol, atol=tol * np.abs(fd).max())

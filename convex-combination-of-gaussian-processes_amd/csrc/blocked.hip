@@ -4,8 +4,12 @@
 //   update : T_ij = A_ij - sum_{k<j} L_ik L_jk'      all tiles i >= j   (f64 MFMA GEMM)
 //   diag   : L_jj = chol(T_jj), W_j = L_jj^-1        one workgroup per matrix, in LDS
 //   trsm   : L_ij = T_ij W_j'                        tiles i > j        (f64 MFMA GEMM)
-// then a forward substitution for [y 1] and the reductions that the reference's
-// dmnorm / beta.MLE need (HX:458-460, HX:570).  Left-looking because every tile is then
+// The right-hand sides [y 1] ride along as an EXTRA (thin) tile row appended below the
+// matrix (rows npad .. npad+127 of an (npad+128) x npad array, two of them used): update
+// and trsm treat it like any other tile row, so when the sweep ends it holds
+// Z' = [y 1]' L^-T, i.e. the forward substitution L z = b is done -- no separate solve
+// pass over the 4n^2 B factor.  A last tiny kernel turns Z and the pivots into what the
+// reference's dmnorm / beta.MLE return (HX:458-460, HX:570).  Left-looking because every tile is then
 // written once and the panels it re-reads are shared through L2 / Infinity Cache: HBM
 // traffic is ~2 x 4n^2 B per matrix instead of the right-looking 8n^3/(3 nb) B, so the
 // trailing update is MFMA-bound, not HBM-bound.
@@ -46,15 +50,115 @@ __device__ inline void decode_block(int L, int ntile, int nb, int& b, int& t) {
   (void)nb;
 }
 
+// One 128 x 128 output tile, C = C - P Q' (update) or C = P Q' (trsm), K-loop over 16-deep LDS
+// stages (double buffered, register-staged global loads issued one stage ahead).
+// THIN = the right-hand-side tile row: only its first 16 rows carry data, so the four waves
+// split the 128 columns (one 16-row x 32-column strip each) instead of 64 x 64 quadrants.
+template <bool THIN>
+__device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
+                                          int ldQ, int Kdim, double* C, int ld, int mode) {
+  constexpr int NX = THIN ? 2 : 4;   // 16-wide column sub-tiles per wave
+  constexpr int NY = THIN ? 1 : 4;   // 16-high row sub-tiles per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = THIN ? 0 : (wave >> 1) * 64;
+  const int col0 = THIN ? wave * 32 : (wave & 1) * 64;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  d4 acc[NX][NY];
+#pragma unroll
+  for (int x = 0; x < NX; ++x)
+#pragma unroll
+    for (int y = 0; y < NY; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // staging: per stage a thread moves 4 x 16 B of P and of Q; a wave covers one whole
+  // 1 KiB column (k = wave + 4 q), so global reads and LDS writes are fully coalesced.
+  // (plain unrolled code on purpose: staging arrays captured by a lambda end up in scratch)
+  const int r2 = lane * 2;
+  const double* pP = P + r2 + (size_t)wave * ldP;
+  const double* pQ = Q + r2 + (size_t)wave * ldQ;
+  const size_t stepP = (size_t)4 * ldP, stepQ = (size_t)4 * ldQ;
+  double2 pr0, pr1, pr2, pr3, qr0, qr1, qr2, qr3;
+#define CCGP_GLOAD()                                            \
+  do {                                                          \
+    pr0 = *reinterpret_cast<const double2*>(pP);                \
+    pr1 = *reinterpret_cast<const double2*>(pP + stepP);        \
+    pr2 = *reinterpret_cast<const double2*>(pP + 2 * stepP);    \
+    pr3 = *reinterpret_cast<const double2*>(pP + 3 * stepP);    \
+    qr0 = *reinterpret_cast<const double2*>(pQ);                \
+    qr1 = *reinterpret_cast<const double2*>(pQ + stepQ);        \
+    qr2 = *reinterpret_cast<const double2*>(pQ + 2 * stepQ);    \
+    qr3 = *reinterpret_cast<const double2*>(pQ + 3 * stepQ);    \
+    pP += 4 * stepP;                                            \
+    pQ += 4 * stepQ;                                            \
+  } while (0)
+#define CCGP_LSTORE(stage)                                                        \
+  do {                                                                            \
+    double* Ps_ = smem + (stage) * kStageDoubles + wave * kLdsRow + r2;           \
+    double* Qs_ = Ps_ + kBK * kLdsRow;                                            \
+    *reinterpret_cast<double2*>(Ps_) = pr0;                                       \
+    *reinterpret_cast<double2*>(Ps_ + 4 * kLdsRow) = pr1;                         \
+    *reinterpret_cast<double2*>(Ps_ + 8 * kLdsRow) = pr2;                         \
+    *reinterpret_cast<double2*>(Ps_ + 12 * kLdsRow) = pr3;                        \
+    *reinterpret_cast<double2*>(Qs_) = qr0;                                       \
+    *reinterpret_cast<double2*>(Qs_ + 4 * kLdsRow) = qr1;                         \
+    *reinterpret_cast<double2*>(Qs_ + 8 * kLdsRow) = qr2;                         \
+    *reinterpret_cast<double2*>(Qs_ + 12 * kLdsRow) = qr3;                        \
+  } while (0)
+
+  const int nk = Kdim / kBK;
+  CCGP_GLOAD();
+  CCGP_LSTORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) CCGP_GLOAD();
+    const double* Ps = smem + (kt & 1) * kStageDoubles;
+    const double* Qs = Ps + kBK * kLdsRow;
+#pragma unroll
+    for (int kk = 0; kk < kBK / 4; ++kk) {
+      double pf[NY], qf[NX];
+      const int krow = (kk * 4 + l4) * kLdsRow;
+#pragma unroll
+      for (int y = 0; y < NY; ++y) pf[y] = Ps[krow + row0 + y * 16 + l15];
+#pragma unroll
+      for (int x = 0; x < NX; ++x) qf[x] = Qs[krow + col0 + x * 16 + l15];
+#pragma unroll
+      for (int x = 0; x < NX; ++x)
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[x], pf[y], acc[x][y], 0, 0, 0);
+    }
+    if (more) CCGP_LSTORE((kt + 1) & 1);
+    __syncthreads();
+  }
+#undef CCGP_GLOAD
+#undef CCGP_LSTORE
+
+  // epilogue: accumulator register r of sub-tile (x, y) is C[row0 + 16y + l15][col0 + 16x + l4 + 4r]
+#pragma unroll
+  for (int x = 0; x < NX; ++x)
+#pragma unroll
+    for (int y = 0; y < NY; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = col0 + x * 16 + l4 + 4 * r;
+        const int row = row0 + y * 16 + l15;
+        double* p = C + row + (size_t)col * ld;
+        if (mode == 0) *p = *p - acc[x][y][r];
+        else *p = acc[x][y][r];
+      }
+}
+
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int ntile = g.mode == 0 ? g.nt - g.j : g.nt - g.j - 1;
+  // tile rows j..nt (update) / j+1..nt (trsm); row nt is the thin right-hand-side tile
+  const int ntile = g.mode == 0 ? g.nt - g.j + 1 : g.nt - g.j;
   int b, t;
   decode_block(blockIdx.x, ntile, g.nb, b, t);
   if (b >= g.nb) return;
   const int i = g.j + t + (g.mode == 0 ? 0 : 1);
   double* Ab = g.A + (size_t)b * g.a_stride;
-  const int ld = g.npad;
+  const int ld = g.npad + kTile;
 
   const double* P;
   const double* Q;
@@ -72,80 +176,8 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(GemmArgs g) {
     Kdim = kTile;
   }
   double* C = Ab + (size_t)i * kTile + (size_t)g.j * kTile * ld;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, l4 = lane >> 4;
-
-  d4 acc[4][4];  // [n-subtile][m-subtile]
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
-
-  // staging: thread loads 4 x double2 of P and of Q per stage; element e = tid + 256 q
-  // -> k = e / 64 (= wave + 4 q), rows 2*(e%64), +1  (one wave = one 1 KiB column)
-  const int r2 = (tid & 63) * 2;
-  double2 pr[4], qr[4];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = kt * kBK + wave + 4 * q;
-      pr[q] = *reinterpret_cast<const double2*>(P + r2 + (size_t)k * ldP);
-      qr[q] = *reinterpret_cast<const double2*>(Q + r2 + (size_t)k * ldQ);
-    }
-  };
-  auto lstore = [&](int stage) {
-    double* Ps = smem + stage * kStageDoubles;
-    double* Qs = Ps + kBK * kLdsRow;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = wave + 4 * q;
-      *reinterpret_cast<double2*>(Ps + k * kLdsRow + r2) = pr[q];
-      *reinterpret_cast<double2*>(Qs + k * kLdsRow + r2) = qr[q];
-    }
-  };
-
-  const int nk = Kdim / kBK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);
-    const double* Ps = smem + (kt & 1) * kStageDoubles;
-    const double* Qs = Ps + kBK * kLdsRow;
-#pragma unroll
-    for (int kk = 0; kk < kBK / 4; ++kk) {
-      double pf[4], qf[4];
-      const int krow = (kk * 4 + l4) * kLdsRow;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        pf[x] = Ps[krow + wm * 64 + x * 16 + l15];
-        qf[x] = Qs[krow + wn * 64 + x * 16 + l15];
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[x], pf[y], acc[x][y], 0, 0, 0);
-    }
-    if (kt + 1 < nk) lstore((kt + 1) & 1);
-    __syncthreads();
-  }
-
-  // epilogue: D[(l4 + 4r)][l15] of sub-tile (x = column block, y = row block)
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = wn * 64 + x * 16 + l4 + 4 * r;
-        const int row = wm * 64 + y * 16 + l15;
-        double* p = C + row + (size_t)col * ld;
-        if (g.mode == 0) *p = *p - acc[x][y][r];
-        else *p = acc[x][y][r];
-      }
+  if (i == g.nt) gemm_tile<true>(smem, P, ldP, Q, ldQ, Kdim, C, ld, g.mode);
+  else gemm_tile<false>(smem, P, ldP, Q, ldQ, Kdim, C, ld, g.mode);
 }
 
 // ---- diagonal block: Cholesky + inverse in LDS ---------------------------------------------
@@ -160,91 +192,129 @@ struct DiagArgs {
   int j, nt, nb, n;
 };
 
+// Register-resident: the 256 threads form a 16 x 16 grid (ty = row class, tx = column class)
+// and own the block 2-D cyclically -- thread (ty, tx) holds entries (ty + 16a, tx + 16b).  The
+// 128 x 128 block is factorised as L' D L'^T with the identity appended as 128 extra rows, so
+// the same rank-1 sweep that eliminates column k also produces L'^-1 (forward substitution of
+// e_t): per column one barrier, one 256-word column broadcast through LDS, and <= 44 FMAs per
+// thread on registers.  Then L = L' D^1/2 and W = L^-1 = D^-1/2 L'^-1 are written out.
 __global__ __launch_bounds__(256) void diag_kernel(DiagArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* T = smem;                 // 128 x 128 column-major
-  double* tmp = T + kTile * kTile;  // 128
-  double* red = tmp + kTile;        // 8
+  __shared__ double colbuf[2][256];
+  __shared__ double dvec[kTile];
+  __shared__ double red[4];
   const int b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* Ab = g.A + (size_t)b * g.a_stride;
-  double* C = Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * g.npad;
+  const int tid = threadIdx.x, ty = tid & 15, tx = tid >> 4;
+  const int ld = g.npad + kTile;
+  double* C = g.A + (size_t)b * g.a_stride + (size_t)g.j * kTile + (size_t)g.j * kTile * ld;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
-  for (int e = tid; e < kTile * kTile; e += 256) {
-    int r = e & (kTile - 1), c = e >> 7;
-    T[e] = r >= c ? C[r + (size_t)c * g.npad] : 0.0;
-  }
-  int bad = 0;
-  for (int k = 0; k < kTile; ++k) {
-    __syncthreads();
-    const double piv = T[k + k * kTile];
-    if (!(piv > 0.0)) { bad = k + 1; break; }
-    const double rinv = 1.0 / piv;
-    const double* colk = T + k * kTile;
-    for (int c = k + 1 + wave; c < kTile; c += 4) {
-      const double lck = colk[c] * rinv;
-      double* colc = T + c * kTile;
-      for (int r = c + lane; r < kTile; r += 64) colc[r] = fma(-colk[r], lck, colc[r]);
+  double M[8][8];  // M[a][b], a >= b: row ty+16a, column tx+16b of the block
+  double I[8][8];  // I[a][b], b >= a: appended identity row ty+16a, column tx+16b
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int r = ty + 16 * a, c = tx + 16 * bb;
+      if (a >= bb) M[a][bb] = r >= c ? C[r + (size_t)c * ld] : 0.0;
+      if (bb >= a) I[a][bb] = r == c ? 1.0 : 0.0;
+    }
+
+  int bad = 0, cur = 0;
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    for (int kk = 0; kk < 16; ++kk) {
+      if (bad) break;
+      const int k = 16 * kb + kk;
+      if (tx == kk) {
+#pragma unroll
+        for (int a = kb; a < 8; ++a) colbuf[cur][ty + 16 * a] = M[a][kb];
+#pragma unroll
+        for (int a = 0; a <= kb; ++a) colbuf[cur][kTile + ty + 16 * a] = I[a][kb];
+      }
+      __syncthreads();
+      const double piv = colbuf[cur][k];
+      if (!(piv > 0.0)) { bad = k + 1; break; }   // uniform: every thread reads the same word
+      const double rinv = 1.0 / piv;
+      if (tid == 0) dvec[k] = piv;
+      double lc[8], lr[8], li[8];
+#pragma unroll
+      for (int bb = kb; bb < 8; ++bb) lc[bb] = colbuf[cur][tx + 16 * bb] * rinv;
+      if (tx <= kk) lc[kb] = 0.0;   // columns <= k are finished
+#pragma unroll
+      for (int a = kb; a < 8; ++a) lr[a] = colbuf[cur][ty + 16 * a];
+      if (ty <= kk) lr[kb] = 0.0;   // rows <= k are finished
+#pragma unroll
+      for (int a = 0; a <= kb; ++a) li[a] = colbuf[cur][kTile + ty + 16 * a];
+#pragma unroll
+      for (int bb = kb; bb < 8; ++bb) {
+#pragma unroll
+        for (int a = bb; a < 8; ++a) M[a][bb] = fma(-lr[a], lc[bb], M[a][bb]);
+#pragma unroll
+        for (int a = 0; a <= kb; ++a) I[a][bb] = fma(-li[a], lc[bb], I[a][bb]);
+      }
+      cur ^= 1;
     }
   }
   __syncthreads();
-  // scale columns: L[r][k] = T[r][k] / sqrt(d_k); accumulate log d_k
+
   double lsum = 0.0;
-  for (int k = wave; k < kTile; k += 4) {
-    const double dk = T[k + k * kTile];
-    const double rs = 1.0 / sqrt(dk);
-    if (lane == 0) lsum += log(dk);
-    for (int r = k + lane; r < kTile; r += 64) {
-      double v = T[r + k * kTile];
-      T[r + k * kTile] = (r == k) ? sqrt(dk) : v * rs;
-    }
-  }
-  if (lane == 0) red[wave] = lsum;
+  if (!bad && tid < kTile) lsum = log(dvec[tid]);
+  for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = lsum;
   __syncthreads();
   if (tid == 0) {
     g.logdet_part[(size_t)b * g.nt + g.j] = bad ? kNaN : (red[0] + red[1] + red[2] + red[3]);
     if (bad && g.status[b] == 0) g.status[b] = g.j * kTile + bad;
   }
-  // write L (poisoned with NaN on failure so that the likelihood comes out NaN)
-  for (int e = tid; e < kTile * kTile; e += 256) {
-    int r = e & (kTile - 1), c = e >> 7;
-    C[r + (size_t)c * g.npad] = bad ? kNaN : T[e];
-  }
-  __syncthreads();
-  // in-place inverse of the lower-triangular L (column sweep from the right, dtrti2 order):
-  //   x_jj = 1 / l_jj ;  x[j+1:, j] = -x_jj * X[j+1:, j+1:] * l[j+1:, j]
-  for (int j = kTile - 1; j >= 0; --j) {
-    if (tid < kTile) tmp[tid] = T[tid + j * kTile];
-    __syncthreads();
-    const double xjj = 1.0 / tmp[j];
-    if (tid < kTile) {
-      const int r = tid;
-      if (r == j) T[r + j * kTile] = xjj;
-      else if (r > j) {
-        double s = 0.0;
-        for (int k = j + 1; k <= r; ++k) s = fma(T[r + k * kTile], tmp[k], s);
-        T[r + j * kTile] = -xjj * s;
-      }
-    }
-    __syncthreads();
-  }
+
   double* W = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile;
-  for (int e = tid; e < kTile * kTile; e += 256) W[e] = bad ? kNaN : T[e];
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) {
+    const int c = tx + 16 * bb;
+    const double dc = bad ? 1.0 : dvec[c];
+    const double sq = sqrt(dc), rs = 1.0 / sq;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int r = ty + 16 * a;   // block row (L) / identity row index t (W)
+      if (a >= bb) {
+        double v = r > c ? M[a][bb] * rs : (r == c ? sq : 0.0);
+        C[r + (size_t)c * ld] = bad ? kNaN : v;   // poisoned on failure -> NaN likelihood
+      }
+      // W[c][t] = z'_t[c] / sqrt(d_c), zero above the diagonal (t = r here)
+      double w = 0.0;
+      if (bb >= a) w = c >= r ? I[a][bb] * rs : 0.0;
+      W[c + (size_t)r * kTile] = bad ? kNaN : w;
+    }
+  }
 }
 
-// ---- forward substitution for [y 1] and the likelihood reductions --------------------------
-struct SolveArgs {
+// ---- right-hand-side rows and the final reductions ---------------------------------------------
+struct RhsArgs {
+  double* A;
+  size_t a_stride;
+  int npad, n;
+  const double* y;
+};
+
+// rows npad..npad+127 of every matrix: y' (zero beyond n), 1' (zero beyond n), zeros
+__global__ void rhs_rows_kernel(RhsArgs g) {
+  const int ld = g.npad + kTile;
+  double* Ab = g.A + (size_t)blockIdx.y * g.a_stride;
+  const int c = blockIdx.x;            // one workgroup of 128 threads per column
+  const int r = threadIdx.x;
+  double v = 0.0;
+  if (c < g.n) v = r == 0 ? g.y[c] : (r == 1 ? 1.0 : 0.0);
+  Ab[g.npad + r + (size_t)c * ld] = v;
+}
+
+struct FinishArgs {
   const double* A;
   size_t a_stride;
   int npad;
-  const double* invd;
-  size_t invd_stride;
   const double* logdet_part;
-  const double* y;
   const double* params;
   int ldp, K;
-  int b0, nt, nb, n;
+  int b0, nt, n;
   double sigma2;
   int mode;
   double* loglik;
@@ -260,68 +330,20 @@ __device__ inline double block_sum(double v, double* red, int tid) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void solve_kernel(SolveArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int npad = g.npad;
-  double* zy = smem;              // npad
-  double* z1 = zy + npad;         // npad
-  double* part = z1 + npad;       // 2 x 2 x 128 partial sums
-  double* rhs = part + 4 * kTile; // 2 x 128
-  double* red = rhs + 2 * kTile;  // 8
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int r = tid & (kTile - 1), half = tid >> 7;
-  const double* Ab = g.A + (size_t)b * g.a_stride;
-  const double* Wb = g.invd + (size_t)b * g.invd_stride;
-
-  for (int jb = 0; jb < g.nt; ++jb) {
-    // rhs = b_jb - sum_{k < jb*128} L[jb*128 + r, k] z[k]   (k split in halves by parity)
-    double sy = 0.0, s1 = 0.0;
-    const double* Lrow = Ab + (size_t)jb * kTile + r;
-    const int kend = jb * kTile;
-#pragma unroll 8
-    for (int k = half; k < kend; k += 2) {
-      const double l = Lrow[(size_t)k * npad];
-      sy = fma(l, zy[k], sy);
-      s1 = fma(l, z1[k], s1);
-    }
-    part[half * 2 * kTile + r] = sy;
-    part[half * 2 * kTile + kTile + r] = s1;
-    __syncthreads();
-    if (tid < kTile) {
-      const int gi = jb * kTile + r;
-      rhs[r] = (gi < g.n ? g.y[gi] : 0.0) - (part[r] + part[2 * kTile + r]);
-      rhs[kTile + r] = (gi < g.n ? 1.0 : 0.0) - (part[kTile + r] + part[3 * kTile + r]);
-    }
-    __syncthreads();
-    // z_jb = W_jb rhs   (W lower triangular, column-major, ld 128); halves split k by parity
-    const double* W = Wb + (size_t)jb * kTile * kTile;
-    sy = 0.0; s1 = 0.0;
-#pragma unroll 8
-    for (int k = half; k <= r; k += 2) {
-      const double w = W[r + k * kTile];
-      sy = fma(w, rhs[k], sy);
-      s1 = fma(w, rhs[kTile + k], s1);
-    }
-    __syncthreads();
-    part[half * 2 * kTile + r] = sy;
-    part[half * 2 * kTile + kTile + r] = s1;
-    __syncthreads();
-    if (tid < kTile) {
-      zy[jb * kTile + r] = part[r] + part[2 * kTile + r];
-      z1[jb * kTile + r] = part[kTile + r] + part[3 * kTile + r];
-    }
-    __syncthreads();
-  }
-
+__global__ __launch_bounds__(256) void finish_kernel(FinishArgs g) {
+  __shared__ double red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ld = g.npad + kTile;
+  const double* zrow = g.A + (size_t)b * g.a_stride + g.npad;   // z_y[c] = zrow[c*ld], z_1[c] = zrow[1 + c*ld]
   double logdet = 0.0;
   for (int jb = tid; jb < g.nt; jb += 256) logdet += g.logdet_part[(size_t)b * g.nt + jb];
   logdet = block_sum(logdet, red, tid);
   double s11 = 0.0, s1y = 0.0, syy = 0.0;
-  for (int k = tid; k < g.n; k += 256) {
-    s11 = fma(z1[k], z1[k], s11);
-    s1y = fma(z1[k], zy[k], s1y);
-    syy = fma(zy[k], zy[k], syy);
+  for (int c = tid; c < g.n; c += 256) {
+    const double zy = zrow[(size_t)c * ld], z1 = zrow[1 + (size_t)c * ld];
+    s11 = fma(z1, z1, s11);
+    s1y = fma(z1, zy, s1y);
+    syy = fma(zy, zy, syy);
   }
   s11 = block_sum(s11, red, tid);
   s1y = block_sum(s1y, red, tid);
@@ -335,7 +357,10 @@ __global__ __launch_bounds__(256) void solve_kernel(SolveArgs g) {
   if (g.mode == 0) {
     beta = s1y / s11;
     double q = 0.0;
-    for (int k = tid; k < g.n; k += 256) { double v = zy[k] - beta * z1[k]; q = fma(v, v, q); }
+    for (int c = tid; c < g.n; c += 256) {
+      const double v = zrow[(size_t)c * ld] - beta * zrow[1 + (size_t)c * ld];
+      q = fma(v, v, q);
+    }
     q = block_sum(q, red, tid);
     ll = -0.5 * (g.n * kLog2Pi + g.n * log(cs) + logdet + q / cs);
   } else {
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(256) void solve_kernel(SolveArgs g) {
 
 size_t blocked_ws_bytes(int npad, int nb) {
   const int nt = npad / kTile;
-  size_t dbl = (size_t)nb * npad * npad + (size_t)nb * nt * kTile * kTile + (size_t)nb * nt + 64;
+  size_t dbl = (size_t)nb * (npad + kTile) * npad + (size_t)nb * nt * kTile * kTile + (size_t)nb * nt + 64;
   return dbl * sizeof(double);
 }
 
@@ -361,7 +386,7 @@ BlockedWs blocked_carve(void* ws, int npad, int nb) {
   const int nt = npad / kTile;
   BlockedWs w{};
   w.A = static_cast<double*>(ws);
-  w.a_stride = (size_t)npad * npad;
+  w.a_stride = (size_t)(npad + kTile) * npad;
   w.invd = w.A + (size_t)nb * w.a_stride;
   w.z = w.invd + (size_t)nb * nt * kTile * kTile;  // logdet partials live here (nb x nt)
   return w;
@@ -376,15 +401,13 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)tile_gemm_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
-    (void)hipFuncSetAttribute((const void*)diag_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
-    (void)hipFuncSetAttribute((const void*)solve_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
     attr_set = true;
   }
   {
     ScopedTimer t(h, CCGP_T_COV);
     launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2);
+    RhsArgs ra{w.A, w.a_stride, npad, n, y};
+    hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
   }
   GemmArgs g{};
   g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
@@ -394,35 +417,32 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
   dg.nb = nb; dg.n = n;
   const size_t gemm_lds = 2 * kStageDoubles * sizeof(double);
-  const size_t diag_lds = (kTile * kTile + kTile + 8) * sizeof(double);
   const int nb8 = round_up(nb, 8);
   for (int j = 0; j < nt; ++j) {
     g.j = j;
     if (j > 0) {
       ScopedTimer t(h, CCGP_T_UPDATE);
       g.mode = 0;
-      hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j)), dim3(256), gemm_lds, s, g);
+      hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j + 1)), dim3(256), gemm_lds, s, g);
     }
     {
       ScopedTimer t(h, CCGP_T_DIAG);
       dg.j = j;
-      hipLaunchKernelGGL(diag_kernel, dim3(nb), dim3(256), diag_lds, s, dg);
+      hipLaunchKernelGGL(diag_kernel, dim3(nb), dim3(256), 0, s, dg);
     }
-    if (j + 1 < nt) {
+    {
       ScopedTimer t(h, CCGP_T_TRSM);
       g.mode = 1;
-      hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j - 1)), dim3(256), gemm_lds, s, g);
+      hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j)), dim3(256), gemm_lds, s, g);
     }
   }
   {
     ScopedTimer t(h, CCGP_T_SOLVE);
-    SolveArgs sa{};
-    sa.A = w.A; sa.a_stride = w.a_stride; sa.npad = npad; sa.invd = w.invd;
-    sa.invd_stride = g.invd_stride; sa.logdet_part = w.z; sa.y = y; sa.params = dv.params;
-    sa.ldp = dv.ldp; sa.K = dv.K; sa.b0 = b0; sa.nt = nt; sa.nb = nb; sa.n = n;
-    sa.sigma2 = sigma2; sa.mode = mean_mode; sa.loglik = loglik; sa.beta = beta; sa.status = status;
-    const size_t solve_lds = ((size_t)2 * npad + 6 * kTile + 8) * sizeof(double);
-    hipLaunchKernelGGL(solve_kernel, dim3(nb), dim3(256), solve_lds, s, sa);
+    FinishArgs fa{};
+    fa.A = w.A; fa.a_stride = w.a_stride; fa.npad = npad; fa.logdet_part = w.z; fa.params = dv.params;
+    fa.ldp = dv.ldp; fa.K = dv.K; fa.b0 = b0; fa.nt = nt; fa.n = n; fa.sigma2 = sigma2;
+    fa.mode = mean_mode; fa.loglik = loglik; fa.beta = beta; fa.status = status;
+    hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, s, fa);
   }
 }
 

@@ -106,8 +106,6 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
     return CCGP_OK;
   }
   const int npad = round_up(n, kTile);
-  if ((size_t)(2 * npad + 6 * kTile + 8) * sizeof(double) > (size_t)kLdsBytes - 64)
-    return fail(h, CCGP_EUNSUPPORTED, "n too large for the single-workgroup forward solve (n <= 9600)");
   const int nbc = blocked_chunk(h, npad, B);
   int rc = ensure_ws(h, blocked_ws_bytes(npad, nbc));
   if (rc) return rc;

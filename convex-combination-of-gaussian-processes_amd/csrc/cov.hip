@@ -138,7 +138,7 @@ void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv,
   CovArgs a{};
   a.A = X; a.Bm = X; a.m = n; a.n = n; a.d = d;
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = b0;
-  a.out = Abase; a.batch_stride = batch_stride; a.ldo = npad; a.mode = mean_mode;
+  a.out = Abase; a.batch_stride = batch_stride; a.ldo = npad + kTile; a.mode = mean_mode;
   a.sigma2 = sigma2; a.tau2 = tau2; a.lower_tiles = 1; a.npad = npad;
   int nt64 = npad / 64;
   dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);

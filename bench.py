@@ -207,7 +207,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    h.enable_timing(True)                                  # per-launch HIP events on the kernel's stream
+    h.enable_timing(os.environ.get("CCGP_BENCH_NOTIMING") is None)   # per-launch HIP events on the kernel's stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -237,6 +237,7 @@ def main():
         }
         if args.workload == "cfg4":
             upd_ms, upd_launches = timing["update"]
+            upd_ms = upd_ms or float("nan")
             flops = update_kernel_flops(n) * B * args.steps          # this rank's launches
             ach = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,

@@ -392,19 +392,13 @@ BlockedWs blocked_carve(void* ws, int npad, int nb) {
   return w;
 }
 
-void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
-                    int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
-                    BlockedWs w, double* loglik, double* beta, int* status) {
-  hipStream_t s = h->stream;
+// One matrix group's whole sweep, enqueued on stream s.  w is already offset to the group.
+static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n, int d, const double* y,
+                          DrawView dv, int b0, int nb, int npad, double sigma2, int mean_mode,
+                          double tau2, BlockedWs w, double* loglik, double* beta, int* status) {
   const int nt = npad / kTile;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)tile_gemm_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
-    attr_set = true;
-  }
   {
-    ScopedTimer t(h, CCGP_T_COV);
+    ScopedTimer t(h, CCGP_T_COV, s);
     launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2);
     RhsArgs ra{w.A, w.a_stride, npad, n, y};
     hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
@@ -421,28 +415,65 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   for (int j = 0; j < nt; ++j) {
     g.j = j;
     if (j > 0) {
-      ScopedTimer t(h, CCGP_T_UPDATE);
+      ScopedTimer t(h, CCGP_T_UPDATE, s);
       g.mode = 0;
       hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j + 1)), dim3(256), gemm_lds, s, g);
     }
     {
-      ScopedTimer t(h, CCGP_T_DIAG);
+      ScopedTimer t(h, CCGP_T_DIAG, s);
       dg.j = j;
       hipLaunchKernelGGL(diag_kernel, dim3(nb), dim3(256), 0, s, dg);
     }
     {
-      ScopedTimer t(h, CCGP_T_TRSM);
+      ScopedTimer t(h, CCGP_T_TRSM, s);
       g.mode = 1;
       hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j)), dim3(256), gemm_lds, s, g);
     }
   }
   {
-    ScopedTimer t(h, CCGP_T_SOLVE);
+    ScopedTimer t(h, CCGP_T_SOLVE, s);
     FinishArgs fa{};
     fa.A = w.A; fa.a_stride = w.a_stride; fa.npad = npad; fa.logdet_part = w.z; fa.params = dv.params;
     fa.ldp = dv.ldp; fa.K = dv.K; fa.b0 = b0; fa.nt = nt; fa.n = n; fa.sigma2 = sigma2;
     fa.mode = mean_mode; fa.loglik = loglik; fa.beta = beta; fa.status = status;
     hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, s, fa);
+  }
+}
+
+void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
+                    int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
+                    BlockedWs w, double* loglik, double* beta, int* status) {
+  const int nt = npad / kTile;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)tile_gemm_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
+    attr_set = true;
+  }
+  // split the nb matrices into independent groups (multiples of 8 matrices: the XCD-aware
+  // block decode keeps 8 matrices per XCD group) and fork them onto the group streams
+  int ng = h->n_groups;
+  if (ng > nb / 8) ng = nb / 8;
+  if (ng < 1) ng = 1;
+  if (ng == 1) {
+    blocked_group(h, h->stream, X, n, d, y, dv, b0, nb, npad, sigma2, mean_mode, tau2, w, loglik, beta,
+                  status);
+    return;
+  }
+  (void)hipEventRecord(h->fork, h->stream);
+  const int per = round_up((nb + ng - 1) / ng, 8);
+  for (int gidx = 0, m0 = 0; m0 < nb; ++gidx, m0 += per) {
+    const int cnt = (nb - m0) < per ? (nb - m0) : per;
+    hipStream_t s = h->gstream[gidx];
+    (void)hipStreamWaitEvent(s, h->fork, 0);
+    BlockedWs wg = w;
+    wg.A = w.A + (size_t)m0 * w.a_stride;
+    wg.invd = w.invd + (size_t)m0 * nt * kTile * kTile;
+    wg.z = w.z + (size_t)m0 * nt;
+    blocked_group(h, s, X, n, d, y, dv, b0 + m0, cnt, npad, sigma2, mean_mode, tau2, wg, loglik, beta,
+                  status);
+    (void)hipEventRecord(h->gjoin[gidx], s);
+    (void)hipStreamWaitEvent(h->stream, h->gjoin[gidx], 0);
   }
 }
 

@@ -19,6 +19,8 @@
 //   D[i = (lane>>4) + 4*r][j = lane&15] for accumulator register r = 0..3.
 // We feed A := Q (the block-column operand) and B := P (the block-row operand), so D's
 // lane index runs along matrix ROWS: a wave's store is 4 columns x 128 contiguous bytes.
+#include <cstdlib>
+
 #include "ccgp_internal.h"
 
 namespace ccgp {
@@ -29,7 +31,6 @@ namespace {
 
 constexpr int kBK = 16;              // k-depth of one LDS stage
 constexpr int kLdsRow = kTile + 16;  // padded row (doubles): 1152 B, conflict-free ds_read_b64
-constexpr int kStageDoubles = 2 * kBK * kLdsRow;
 
 struct GemmArgs {
   double* A;
@@ -39,29 +40,31 @@ struct GemmArgs {
   size_t invd_stride;
   int j, nt, nb;
   int mode;  // 0: update, 1: trsm
+  int exp;   // timing experiments only (CCGP_EXP): 1 = read P from the L2-hot Q panel
 };
 
-__device__ inline void decode_block(int L, int ntile, int nb, int& b, int& t) {
-  // XCD-aware: blocks are dealt round-robin over the 8 XCDs, so L % 8 labels the XCD
-  // group.  Keep every tile of one matrix in one group: they share the Q panel in L2.
-  int grp = L / (8 * ntile), r = L % (8 * ntile);
-  b = grp * 8 + (r & 7);
-  t = r >> 3;
-  (void)nb;
-}
-
-// One 128 x 128 output tile, C = C - P Q' (update) or C = P Q' (trsm), K-loop over 16-deep LDS
-// stages (double buffered, register-staged global loads issued one stage ahead).
-// THIN = the right-hand-side tile row: only its first 16 rows carry data, so the four waves
-// split the 128 columns (one 16-row x 32-column strip each) instead of 64 x 64 quadrants.
-template <bool THIN>
+// One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
+// (128 / S) columns per workgroup, K-loop over 16-deep LDS stages (double buffered,
+// register-staged global loads issued one stage ahead).
+//   S = 1: 2 x 2 waves of 64 x 64      S = 2: 2 x 2 waves of 64 x 32      S = 4: 4 x 1 waves of 32 x 32
+// S > 1 exists for wave quantisation: a launch whose workgroup count is 512 m + (a few) would
+// leave the chip mostly idle for a whole tile time; cutting every tile into S column strips
+// shortens that tail S-fold at the price of re-reading the P panel S times through L2.
+// THIN = the right-hand-side tile row: only its first 16 rows carry data, so the waves split
+// the strip's columns between them (16 rows x 32 / 16 / 16 columns per wave for S = 1 / 2 / 4).
+template <int S, bool THIN>
 __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
-                                          int ldQ, int Kdim, double* C, int ld, int mode) {
-  constexpr int NX = THIN ? 2 : 4;   // 16-wide column sub-tiles per wave
-  constexpr int NY = THIN ? 1 : 4;   // 16-high row sub-tiles per wave
+                                          int ldQ, int Kdim, double* C, int ld, int mode, int exp = 0) {
+  constexpr int CW = kTile / S;                         // columns handled by this workgroup
+  constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);   // 16-wide column sub-tiles per wave
+  constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);       // 16-high row sub-tiles per wave
+  constexpr int QROW = CW + 16;                         // padded LDS row of the Q stage (doubles)
+  constexpr int STAGE = kBK * kLdsRow + kBK * QROW;     // doubles per stage
+  constexpr int QLD = CW / 32;                          // double2 loads of Q per thread per stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = THIN ? 0 : (wave >> 1) * 64;
-  const int col0 = THIN ? wave * 32 : (wave & 1) * 64;
+  const int row0 = THIN ? 0 : (S == 4 ? wave * 32 : (wave >> 1) * 64);
+  const int col0 = THIN ? wave * NX * 16 : (S == 4 ? 0 : (wave & 1) * (S == 1 ? 64 : 32));
+  const bool active = !THIN || col0 < CW;               // S = 4 thin strips occupy two waves only
   const int l15 = lane & 15, l4 = lane >> 4;
 
   d4 acc[NX][NY];
@@ -70,39 +73,49 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
 #pragma unroll
     for (int y = 0; y < NY; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
 
-  // staging: per stage a thread moves 4 x 16 B of P and of Q; a wave covers one whole
-  // 1 KiB column (k = wave + 4 q), so global reads and LDS writes are fully coalesced.
-  // (plain unrolled code on purpose: staging arrays captured by a lambda end up in scratch)
+  // staging (plain unrolled code on purpose: arrays captured by a lambda end up in scratch).
+  // P: 128 rows x 16 k per stage = 4 x 16 B per thread; a wave covers one whole 1 KiB column.
+  // Q: CW rows x 16 k per stage = QLD x 16 B per thread; thread t -> k = t / (CW/2), rows 2 (t % (CW/2)).
   const int r2 = lane * 2;
   const double* pP = P + r2 + (size_t)wave * ldP;
-  const double* pQ = Q + r2 + (size_t)wave * ldQ;
-  const size_t stepP = (size_t)4 * ldP, stepQ = (size_t)4 * ldQ;
+  const size_t stepP = (size_t)4 * ldP;
+  constexpr int QT = CW / 2;                 // threads per Q column
+  constexpr int QK = 256 / QT;               // Q columns covered per pass
+  const int qrow2 = (tid % QT) * 2, qk = tid / QT;
+  const double* pQ = Q + qrow2 + (size_t)qk * ldQ;
+  const size_t stepQ = (size_t)QK * ldQ;
+  // (scalars, not arrays: hipcc keeps staging ARRAYS that live across the `if (more)` in scratch)
   double2 pr0, pr1, pr2, pr3, qr0, qr1, qr2, qr3;
-#define CCGP_GLOAD()                                            \
-  do {                                                          \
-    pr0 = *reinterpret_cast<const double2*>(pP);                \
-    pr1 = *reinterpret_cast<const double2*>(pP + stepP);        \
-    pr2 = *reinterpret_cast<const double2*>(pP + 2 * stepP);    \
-    pr3 = *reinterpret_cast<const double2*>(pP + 3 * stepP);    \
-    qr0 = *reinterpret_cast<const double2*>(pQ);                \
-    qr1 = *reinterpret_cast<const double2*>(pQ + stepQ);        \
-    qr2 = *reinterpret_cast<const double2*>(pQ + 2 * stepQ);    \
-    qr3 = *reinterpret_cast<const double2*>(pQ + 3 * stepQ);    \
-    pP += 4 * stepP;                                            \
-    pQ += 4 * stepQ;                                            \
+  qr1 = qr2 = qr3 = double2{0.0, 0.0};
+#define CCGP_GLOAD()                                                              \
+  do {                                                                            \
+    pr0 = *reinterpret_cast<const double2*>(pP);                                  \
+    pr1 = *reinterpret_cast<const double2*>(pP + stepP);                          \
+    pr2 = *reinterpret_cast<const double2*>(pP + 2 * stepP);                      \
+    pr3 = *reinterpret_cast<const double2*>(pP + 3 * stepP);                      \
+    qr0 = *reinterpret_cast<const double2*>(pQ);                                  \
+    if constexpr (QLD > 1) qr1 = *reinterpret_cast<const double2*>(pQ + stepQ);   \
+    if constexpr (QLD > 2) {                                                      \
+      qr2 = *reinterpret_cast<const double2*>(pQ + 2 * stepQ);                    \
+      qr3 = *reinterpret_cast<const double2*>(pQ + 3 * stepQ);                    \
+    }                                                                             \
+    pP += 4 * stepP;                                                              \
+    pQ += QLD * stepQ;                                                            \
   } while (0)
 #define CCGP_LSTORE(stage)                                                        \
   do {                                                                            \
-    double* Ps_ = smem + (stage) * kStageDoubles + wave * kLdsRow + r2;           \
-    double* Qs_ = Ps_ + kBK * kLdsRow;                                            \
+    double* Ps_ = smem + (stage) * STAGE + wave * kLdsRow + r2;                   \
+    double* Qs_ = smem + (stage) * STAGE + kBK * kLdsRow + qk * QROW + qrow2;     \
     *reinterpret_cast<double2*>(Ps_) = pr0;                                       \
     *reinterpret_cast<double2*>(Ps_ + 4 * kLdsRow) = pr1;                         \
     *reinterpret_cast<double2*>(Ps_ + 8 * kLdsRow) = pr2;                         \
     *reinterpret_cast<double2*>(Ps_ + 12 * kLdsRow) = pr3;                        \
     *reinterpret_cast<double2*>(Qs_) = qr0;                                       \
-    *reinterpret_cast<double2*>(Qs_ + 4 * kLdsRow) = qr1;                         \
-    *reinterpret_cast<double2*>(Qs_ + 8 * kLdsRow) = qr2;                         \
-    *reinterpret_cast<double2*>(Qs_ + 12 * kLdsRow) = qr3;                        \
+    if constexpr (QLD > 1) *reinterpret_cast<double2*>(Qs_ + QK * QROW) = qr1;    \
+    if constexpr (QLD > 2) {                                                      \
+      *reinterpret_cast<double2*>(Qs_ + 2 * QK * QROW) = qr2;                     \
+      *reinterpret_cast<double2*>(Qs_ + 3 * QK * QROW) = qr3;                     \
+    }                                                                             \
   } while (0)
 
   const int nk = Kdim / kBK;
@@ -110,31 +123,33 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
   CCGP_LSTORE(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
+    const bool more = (kt + 1 < nk) && exp != 7 && exp != 8;   // exp 7/8: timing experiments only
     if (more) CCGP_GLOAD();
-    const double* Ps = smem + (kt & 1) * kStageDoubles;
+    const double* Ps = smem + (kt & 1) * STAGE;
     const double* Qs = Ps + kBK * kLdsRow;
 #pragma unroll
     for (int kk = 0; kk < kBK / 4; ++kk) {
       double pf[NY], qf[NX];
-      const int krow = (kk * 4 + l4) * kLdsRow;
 #pragma unroll
-      for (int y = 0; y < NY; ++y) pf[y] = Ps[krow + row0 + y * 16 + l15];
+      for (int y = 0; y < NY; ++y) pf[y] = Ps[(kk * 4 + l4) * kLdsRow + row0 + y * 16 + l15];
 #pragma unroll
-      for (int x = 0; x < NX; ++x) qf[x] = Qs[krow + col0 + x * 16 + l15];
+      for (int x = 0; x < NX; ++x) qf[x] = Qs[(kk * 4 + l4) * QROW + col0 + x * 16 + l15];
+      if (active) {
 #pragma unroll
-      for (int x = 0; x < NX; ++x)
+        for (int x = 0; x < NX; ++x)
 #pragma unroll
-        for (int y = 0; y < NY; ++y)
-          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[x], pf[y], acc[x][y], 0, 0, 0);
+          for (int y = 0; y < NY; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[x], pf[y], acc[x][y], 0, 0, 0);
+      }
     }
     if (more) CCGP_LSTORE((kt + 1) & 1);
-    __syncthreads();
+    if (exp != 6 && exp != 8) __syncthreads();
   }
 #undef CCGP_GLOAD
 #undef CCGP_LSTORE
 
   // epilogue: accumulator register r of sub-tile (x, y) is C[row0 + 16y + l15][col0 + 16x + l4 + 4r]
+  if (!active) return;
 #pragma unroll
   for (int x = 0; x < NX; ++x)
 #pragma unroll
@@ -149,35 +164,100 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
       }
 }
 
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+template <int S>
+constexpr size_t gemm_lds_bytes() {
+  return sizeof(double) * 2 * (kBK * kLdsRow + kBK * (kTile / S + 16));
+}
+
+template <int MODE, int S>
+__device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   // tile rows j..nt (update) / j+1..nt (trsm); row nt is the thin right-hand-side tile
-  const int ntile = g.mode == 0 ? g.nt - g.j + 1 : g.nt - g.j;
-  int b, t;
-  decode_block(blockIdx.x, ntile, g.nb, b, t);
+  const int ntile = MODE == 0 ? g.nt - g.j + 1 : g.nt - g.j;
+  // block index -> (matrix, tile, strip): strips of a tile adjacent, tiles of a matrix on one
+  // XCD group (blocks are dealt round-robin over the 8 XCDs, so index % 8 labels the group and
+  // all tiles of one matrix share the Q panel in that XCD's L2)
+  const int L = blockIdx.x;
+  const int per_grp = 8 * ntile * S;
+  const int grp = L / per_grp, r = L % per_grp;
+  const int b = grp * 8 + (r & 7);
+  const int t = (r >> 3) / S, strip = (r >> 3) % S;
   if (b >= g.nb) return;
-  const int i = g.j + t + (g.mode == 0 ? 0 : 1);
+  const int i = g.j + t + (MODE == 0 ? 0 : 1);
+  const bool thin = i == g.nt;
   double* Ab = g.A + (size_t)b * g.a_stride;
   const int ld = g.npad + kTile;
+  const int c0 = strip * (kTile / S);   // first column of this strip inside the tile
 
   const double* P;
   const double* Q;
   int ldP, ldQ, Kdim;
-  if (g.mode == 0) {
-    P = Ab + (size_t)i * kTile;
-    Q = Ab + (size_t)g.j * kTile;
+  if (MODE == 0) {
+    P = Ab + (size_t)(g.exp == 1 ? g.j : i) * kTile;
+    Q = Ab + (size_t)g.j * kTile + c0;
     ldP = ldQ = ld;
     Kdim = g.j * kTile;
   } else {
     P = Ab + (size_t)i * kTile + (size_t)g.j * kTile * ld;
-    Q = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile;
+    Q = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile + c0;
     ldP = ld;
     ldQ = kTile;
     Kdim = kTile;
   }
-  double* C = Ab + (size_t)i * kTile + (size_t)g.j * kTile * ld;
-  if (i == g.nt) gemm_tile<true>(smem, P, ldP, Q, ldQ, Kdim, C, ld, g.mode);
-  else gemm_tile<false>(smem, P, ldP, Q, ldQ, Kdim, C, ld, g.mode);
+  double* C = Ab + (size_t)i * kTile + ((size_t)g.j * kTile + c0) * ld;
+  // experiments: de-phase the workgroups that share a CU (they run identical code and would
+  // otherwise reach their per-stage barrier together, idling the MFMA pipe)
+  if (g.exp >= 2) {
+    const int bit = g.exp == 2 ? (L >> 8) & 1 : (g.exp == 3 ? (L >> 9) & 1 : (g.exp == 4 ? (L >> 3) & 1 : (L >> 11) & 1));
+    if (__builtin_amdgcn_readfirstlane(bit)) __builtin_amdgcn_s_sleep(64);
+  }
+  if (thin) gemm_tile<S, true>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE, g.exp);
+  else gemm_tile<S, false>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE, g.exp);
+}
+
+// distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
+#define CCGP_DEFINE_GEMM(NAME, MODE, S, WPS)                                            \
+  __global__ __launch_bounds__(256, WPS) void NAME(GemmArgs g) {                        \
+    extern __shared__ __attribute__((aligned(16))) double smem[];                       \
+    gemm_dispatch<MODE, S>(g, smem);                                                     \
+  }
+CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2)
+CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
+CCGP_DEFINE_GEMM(chol_update_s4_kernel, 0, 4, 3)
+CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
+CCGP_DEFINE_GEMM(chol_trsm_s2_kernel, 1, 2, 2)
+CCGP_DEFINE_GEMM(chol_trsm_s4_kernel, 1, 4, 3)
+#undef CCGP_DEFINE_GEMM
+
+// Strip count for an update launch: minimise ceil(workgroups / resident slots) x time per
+// workgroup.  Slots per chip (2 / 2 / 3 workgroups per CU by LDS) and the relative per-flop
+// efficiency of the narrower strips (1 / 0.85 / 0.70) were fitted to per-launch rocprof
+// timings on MI355X (profiles/r01c_strip_selection.md): within 0.5 % of the per-launch optimum.
+static int pick_strips(int tiles) {
+  const int slots[3] = {512, 512, 768};
+  const double eff[3] = {1.0, 0.85, 0.70};
+  int best = 1;
+  double best_cost = 1e300;
+  for (int q = 0; q < 3; ++q) {
+    const int S = 1 << q;
+    const double cost = (double)((tiles * S + slots[q] - 1) / slots[q]) / (S * eff[q]);
+    if (cost < best_cost) { best_cost = cost; best = S; }
+  }
+  return best;
+}
+
+static void launch_gemm(hipStream_t s, const GemmArgs& g, int mode, int S) {
+  const int ntile = mode == 0 ? g.nt - g.j + 1 : g.nt - g.j;
+  const int nb8 = round_up(g.nb, 8);
+  const dim3 grid(nb8 * ntile * S), block(256);
+  if (mode == 0) {
+    if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
+    else if (S == 2) hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
+    else hipLaunchKernelGGL(chol_update_s4_kernel, grid, block, gemm_lds_bytes<4>(), s, g);
+  } else {
+    if (S == 1) hipLaunchKernelGGL(chol_trsm_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
+    else if (S == 2) hipLaunchKernelGGL(chol_trsm_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
+    else hipLaunchKernelGGL(chol_trsm_s4_kernel, grid, block, gemm_lds_bytes<4>(), s, g);
+  }
 }
 
 // ---- diagonal block: Cholesky + inverse in LDS ---------------------------------------------
@@ -410,14 +490,20 @@ static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n,
   dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
   dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
   dg.nb = nb; dg.n = n;
-  const size_t gemm_lds = 2 * kStageDoubles * sizeof(double);
-  const int nb8 = round_up(nb, 8);
+  static int force_s = -1, exp_mode = 0;
+  if (force_s < 0) {
+    const char* e = getenv("CCGP_STRIPS");
+    force_s = e ? atoi(e) : 0;
+    const char* x = getenv("CCGP_EXP");
+    exp_mode = x ? atoi(x) : 0;
+  }
+  g.exp = exp_mode;
   for (int j = 0; j < nt; ++j) {
     g.j = j;
     if (j > 0) {
       ScopedTimer t(h, CCGP_T_UPDATE, s);
       g.mode = 0;
-      hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j + 1)), dim3(256), gemm_lds, s, g);
+      launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8) * (nt - j + 1)));
     }
     {
       ScopedTimer t(h, CCGP_T_DIAG, s);
@@ -427,7 +513,7 @@ static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n,
     {
       ScopedTimer t(h, CCGP_T_TRSM, s);
       g.mode = 1;
-      hipLaunchKernelGGL(tile_gemm_kernel, dim3(nb8 * (nt - j)), dim3(256), gemm_lds, s, g);
+      launch_gemm(s, g, 1, 1);   // trsm is in place: strips of one tile would race (read-all / write-own)
     }
   }
   {
@@ -446,8 +532,11 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   const int nt = npad / kTile;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)tile_gemm_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
+    const void* ks[] = {(const void*)chol_update_kernel, (const void*)chol_update_s2_kernel,
+                        (const void*)chol_update_s4_kernel, (const void*)chol_trsm_kernel,
+                        (const void*)chol_trsm_s2_kernel, (const void*)chol_trsm_s4_kernel};
+    for (const void* k : ks)
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
     attr_set = true;
   }
   // split the nb matrices into independent groups (multiples of 8 matrices: the XCD-aware

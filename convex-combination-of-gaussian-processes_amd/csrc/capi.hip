@@ -101,8 +101,13 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
   DrawView dv{dparams, B, K, d};
   if (n <= kSmallMaxN) {
     ScopedTimer t(h, CCGP_T_FUSED);
-    launch_small_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
-                        d_status);
+    static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
+    if (small_reg_supported(n, d) && !force_lds)
+      launch_small_reg_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
+                              d_status);
+    else
+      launch_small_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
+                          d_status);
     CCGP_HIP(hipGetLastError());
     return CCGP_OK;
   }

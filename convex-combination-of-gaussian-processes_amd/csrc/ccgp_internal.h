@@ -93,6 +93,12 @@ void launch_small_grad(hipStream_t s, const double* X, int n, int d, const doubl
                        int B, double sigma2, double* loglik, double* beta, double* grad,
                        int* status, double* gpart);
 
+// ---- small_reg.hip: register-resident evaluator for the plain likelihood (n <= 128) ---------
+bool small_reg_supported(int n, int d);
+void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
+                             int B, double sigma2, int mean_mode, double tau2, double* loglik,
+                             double* beta, int* status);
+
 // ---- blocked.hip ---------------------------------------------------------------------
 struct BlockedWs {
   double* A;        // nb x npad x npad (lower tiles used)

@@ -1,0 +1,273 @@
+// Register-resident fused evaluator for the plain likelihood at n <= 128 (BASELINE configs 2
+// and 3: the hyperprior grids, HX:549-595 / ADV:552-599; and the likelihood term of logpost).
+//
+// A G x G grid of threads owns ONE matrix 2-D cyclically in registers: thread (ty, tx) holds
+// entries (ty + G a, tx + G b), a >= b, plus one block row of right-hand sides (row ty = 0 is
+// y', row ty = 1 is 1').  The covariance is generated straight into those registers (never in
+// HBM, never in LDS), then eliminated as L' D L'^T: per column, the owning threads publish the
+// column through a 2 x (n + G)-word LDS buffer and every thread applies its rank-1 update on
+// registers.  The right-hand-side row is updated like any other row, so the forward
+// substitutions come for free (same scheme as small.hip, which keeps the matrix in LDS and
+// also serves prediction / inverse / gradient).
+//   G = 8 : one WAVE per matrix, no s_barrier at all (LDS traffic of one wave is ordered), four
+//           matrices per workgroup -- n <= 64 (Heat-Exchanger grid, n = 64)
+//   G = 16: one workgroup per matrix, one barrier per column -- 64 < n <= 128
+// NB = ceil(n / G) is a template parameter so that every register index is static.
+//
+// Bound: neither HBM nor MFMA -- n dependent elimination steps; algorithmic HBM traffic per
+// evaluation is the parameter row in (8 P bytes) and 20 bytes out.
+#include "ccgp_internal.h"
+
+namespace ccgp {
+
+namespace {
+
+struct RegArgs {
+  const double* X;
+  const double* y;
+  int n, d;
+  const double* params;
+  int ldp, K;
+  int draw0, B;
+  double sigma2;
+  int mode;
+  double tau2;
+  double* loglik;
+  double* beta;
+  int* status;
+};
+
+constexpr int kPerMat(int NP, int G) {  // doubles of LDS per matrix
+  return kMaxK * NP /*us*/ + kMaxK * kMaxD /*th*/ + kMaxK /*w2*/ + 2 * (NP + G) /*colbuf*/ + NP /*dvec*/ +
+         2 * NP /*zb*/ + 8;
+}
+
+template <int G>
+__device__ __forceinline__ void mat_sync() {
+  if constexpr (G == 16) {
+    __syncthreads();
+  } else {
+    // one wave per matrix: its LDS operations are processed in order; only the compiler has to
+    // be kept from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int G, int NB>
+__global__ __launch_bounds__(256) void small_reg_kernel(RegArgs a) {
+  constexpr int TPM = G * G;       // threads per matrix
+  constexpr int MPW = 256 / TPM;   // matrices per workgroup
+  constexpr int NP = G * NB;       // padded order
+  constexpr int PM = kPerMat(NP, G);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int n = a.n, d = a.d, K = a.K;
+  const int tid = threadIdx.x, sub = tid / TPM, lt = tid % TPM;
+  const int ty = lt % G, tx = lt / G;
+  int b = a.draw0 + blockIdx.x * MPW + sub;
+  const bool valid = b < a.draw0 + a.B;
+  if (!valid) b = a.draw0 + a.B - 1;   // keep the wave alive (shared loads, barriers); results discarded
+
+  double* xs = smem;                          // d x n, shared by the matrices of this workgroup
+  double* mine = xs + d * n + (size_t)sub * PM;
+  double* us = mine;
+  double* th = us + kMaxK * NP;
+  double* w2 = th + kMaxK * kMaxD;
+  double* colbuf = w2 + kMaxK;                // [2][NP + G]
+  double* dvec = colbuf + 2 * (NP + G);
+  double* zb = dvec + NP;                     // [2][NP]
+
+  for (int e = tid; e < n * d; e += 256) xs[e] = a.X[e];
+  for (int e = lt; e < K * d; e += TPM) th[e] = a.params[b + (size_t)(K + e) * a.ldp];
+  if (lt < K) {
+    const double w = a.params[b + (size_t)lt * a.ldp];
+    w2[lt] = w * w;
+  }
+  __syncthreads();
+  for (int e = lt; e < K * n; e += TPM) {
+    const int c = e / n, i = e % n;
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) { const double v = xs[k * n + i]; s += v * v * th[c * d + k]; }
+    us[c * NP + i] = s;
+  }
+  __syncthreads();
+
+  double sw = 0.0;
+  for (int c = 0; c < K; ++c) sw += w2[c];
+  const double cs = a.sigma2 * sw;
+  const double post_scale = a.mode == 1 ? cs : 1.0;
+  const double post_shift = a.mode == 1 ? a.tau2 : 0.0;
+
+  // ---- generate the lower triangle and the right-hand-side row into registers ------------------
+  double M[NB][NB];  // M[a][b], a >= b
+  double E[NB];      // row ty of the right-hand-side block: ty = 0 -> y', ty = 1 -> 1'
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    const int c = tx + G * bb;
+#pragma unroll
+    for (int aa = bb; aa < NB; ++aa) {
+      const int r = ty + G * aa;
+      double v;
+      if (r < n && c < n) {
+        if (r >= c) {
+          double acc = 0.0;
+          for (int q = 0; q < K; ++q) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s = fma(xs[k * n + r] * th[q * d + k], xs[k * n + c], s);
+            const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * s);
+            acc += w2[q] * exp(-dist);
+          }
+          v = post_scale * (acc / sw) + post_shift;
+        } else {
+          v = 0.0;  // strictly upper entry of a diagonal block: never read
+        }
+      } else {
+        v = r == c ? 1.0 : 0.0;  // identity on the padding
+      }
+      M[aa][bb] = v;
+    }
+    E[bb] = c < n ? (ty == 0 ? a.y[c] : (ty == 1 ? 1.0 : 0.0)) : 0.0;
+  }
+
+  // ---- L' D L'^T on registers; one column broadcast through LDS per step ------------------------
+  int bad = 0, cur = 0;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    for (int kk = 0; kk < G; ++kk) {
+      const int k = G * kb + kk;
+      if (bad || k >= n) break;
+      double* cb = colbuf + cur * (NP + G);
+      if (tx == kk) {
+#pragma unroll
+        for (int aa = kb; aa < NB; ++aa) cb[ty + G * aa] = M[aa][kb];
+        cb[NP + ty] = E[kb];
+      }
+      mat_sync<G>();
+      const double piv = cb[k];
+      if (!(piv > 0.0)) { bad = k + 1; break; }   // uniform over the matrix's threads
+      const double rinv = 1.0 / piv;
+      if (lt == 0) dvec[k] = piv;
+      double lc[NB], lr[NB];
+#pragma unroll
+      for (int bb = kb; bb < NB; ++bb) lc[bb] = cb[tx + G * bb] * rinv;
+      if (tx <= kk) lc[kb] = 0.0;   // columns <= k are finished
+#pragma unroll
+      for (int aa = kb; aa < NB; ++aa) lr[aa] = cb[ty + G * aa];
+      if (ty <= kk) lr[kb] = 0.0;   // rows <= k are finished
+      const double le = cb[NP + ty];
+#pragma unroll
+      for (int bb = kb; bb < NB; ++bb) {
+#pragma unroll
+        for (int aa = bb; aa < NB; ++aa) M[aa][bb] = fma(-lr[aa], lc[bb], M[aa][bb]);
+        E[bb] = fma(-le, lc[bb], E[bb]);
+      }
+      cur ^= 1;
+    }
+  }
+  // z'_y[c] and z'_1[c] sit in threads ty = 0 / 1
+  if (ty < 2) {
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) zb[ty * NP + tx + G * bb] = E[bb];
+  }
+  mat_sync<G>();
+
+  // ---- reductions (first wave of the matrix's threads) --------------------------------------------
+  if (lt < 64) {
+    const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+    double logdet = 0.0, s11 = 0.0, s1y = 0.0, syy = 0.0;
+    if (!bad)
+      for (int k = lt; k < n; k += 64) {
+        const double dk = dvec[k], zy = zb[k], z1 = zb[NP + k];
+        logdet += log(dk);
+        s11 += z1 * z1 / dk;
+        s1y += z1 * zy / dk;
+        syy += zy * zy / dk;
+      }
+    for (int off = 32; off > 0; off >>= 1) {
+      logdet += __shfl_xor(logdet, off, 64);
+      s11 += __shfl_xor(s11, off, 64);
+      s1y += __shfl_xor(s1y, off, 64);
+      syy += __shfl_xor(syy, off, 64);
+    }
+    const double kLog2Pi = 1.8378770664093454835606594728112;
+    double beta = 0.0, ll;
+    if (a.mode == 0) {
+      beta = s1y / s11;
+      double q = 0.0;
+      if (!bad)
+        for (int k = lt; k < n; k += 64) {
+          const double r = zb[k] - beta * zb[NP + k];
+          q += r * r / dvec[k];
+        }
+      for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+      ll = -0.5 * (n * kLog2Pi + n * log(cs) + logdet + q / cs);
+    } else {
+      ll = -0.5 * (n * kLog2Pi + logdet + syy);
+    }
+    if (bad) { ll = kNaN; beta = kNaN; }
+    if (lt == 0 && valid) {
+      a.loglik[b] = ll;
+      if (a.beta) a.beta[b] = beta;
+      if (a.status) a.status[b] = bad;
+    }
+  }
+}
+
+template <int G, int NB>
+void launch_one(hipStream_t s, const RegArgs& a) {
+  constexpr int MPW = 256 / (G * G);
+  const size_t lds = sizeof(double) * ((size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)small_reg_kernel<G, NB>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
+    attr_set = true;
+  }
+  const int kMaxGrid = 1 << 20;
+  RegArgs c = a;
+  for (int b0 = 0; b0 < a.B; b0 += kMaxGrid * MPW) {
+    c.draw0 = a.draw0 + b0;
+    c.B = a.B - b0 < kMaxGrid * MPW ? a.B - b0 : kMaxGrid * MPW;
+    hipLaunchKernelGGL((small_reg_kernel<G, NB>), dim3((c.B + MPW - 1) / MPW), dim3(256), lds, s, c);
+  }
+}
+
+}  // namespace
+
+bool small_reg_supported(int n, int d) {
+  if (n > 128) return false;
+  const int G = n <= 64 ? 8 : 16;
+  const int NB = (n + G - 1) / G;
+  const int MPW = 256 / (G * G);
+  return sizeof(double) * ((size_t)d * n + (size_t)MPW * kPerMat(G * NB, G)) <= (size_t)kLdsBytes - 64;
+}
+
+void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
+                             int B, double sigma2, int mean_mode, double tau2, double* loglik,
+                             double* beta, int* status) {
+  RegArgs a{};
+  a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
+  a.draw0 = 0; a.B = B; a.sigma2 = sigma2; a.mode = mean_mode; a.tau2 = tau2;
+  a.loglik = loglik; a.beta = beta; a.status = status;
+  if (n <= 64) {
+    switch ((n + 7) / 8) {
+      case 1: launch_one<8, 1>(s, a); break;
+      case 2: launch_one<8, 2>(s, a); break;
+      case 3: launch_one<8, 3>(s, a); break;
+      case 4: launch_one<8, 4>(s, a); break;
+      case 5: launch_one<8, 5>(s, a); break;
+      case 6: launch_one<8, 6>(s, a); break;
+      case 7: launch_one<8, 7>(s, a); break;
+      default: launch_one<8, 8>(s, a); break;
+    }
+  } else {
+    switch ((n + 15) / 16) {
+      case 5: launch_one<16, 5>(s, a); break;
+      case 6: launch_one<16, 6>(s, a); break;
+      case 7: launch_one<16, 7>(s, a); break;
+      default: launch_one<16, 8>(s, a); break;
+    }
+  }
+}
+
+}  // namespace ccgp

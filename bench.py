@@ -98,6 +98,17 @@ def update_kernel_flops(n):
     return sum(j * t3 * ((nt - 1 - j) + 0.5) for j in range(1, nt))
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (counters cannot
+    be read from inside the process; collected separately exactly as the MI355X guide prescribes)."""
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/r01d_pmc_traffic.json"
+    except Exception:
+        return None, None
+
+
 # ----------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2, budget_s=20.0):
     """The oracle (numpy restatement of the reference's R operation sequence: materialised
@@ -240,9 +251,12 @@ def main():
             upd_ms = upd_ms or float("nan")
             flops = update_kernel_flops(n) * B * args.steps          # this rank's launches
             ach = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+            traffic, traffic_src = pmc_traffic("chol_update") if (n == 4096 and B == 64) else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "tile_gemm_kernel (mode 0: blocked-Cholesky trailing update)",
+                               "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
+                               "traffic_source": traffic_src,
+                               "kernel": "chol_update*_kernel (blocked-Cholesky trailing update, f64 MFMA)",
                                "launches": upd_launches,
                                "avg_launch_ms": upd_ms / max(upd_launches, 1),
                                "flops_per_launch": flops / max(upd_launches, 1)}
@@ -253,7 +267,8 @@ def main():
             ach = flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "small_kernel (fused in-LDS evaluator; latency-bound, see DESIGN.md)",
+                               "kernel": "small_reg_kernel (register-resident fused evaluator; bounded by its n-step "
+                                         "dependency chain, neither HBM nor MFMA -- see DESIGN.md)",
                                "launches": fl, "avg_launch_ms": fused_ms / max(fl, 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, X, y, P, K, sigma2, mode, tau2)

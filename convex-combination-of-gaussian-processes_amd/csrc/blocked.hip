@@ -39,8 +39,9 @@ struct GemmArgs {
   double* invd;
   size_t invd_stride;
   int j, nt, nb;
+  int ld;    // leading dimension = npad + 128 (right-hand-side tile row) + 128 * ne
+  int ne;    // extra full tile rows below the right-hand-side row (cross-correlation rows)
   int mode;  // 0: update, 1: trsm
-  int exp;   // timing experiments only (CCGP_EXP): 1 = read P from the L2-hot Q panel
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
@@ -54,7 +55,7 @@ struct GemmArgs {
 // the strip's columns between them (16 rows x 32 / 16 / 16 columns per wave for S = 1 / 2 / 4).
 template <int S, bool THIN>
 __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
-                                          int ldQ, int Kdim, double* C, int ld, int mode, int exp = 0) {
+                                          int ldQ, int Kdim, double* C, int ld, int mode) {
   constexpr int CW = kTile / S;                         // columns handled by this workgroup
   constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);   // 16-wide column sub-tiles per wave
   constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);       // 16-high row sub-tiles per wave
@@ -123,7 +124,7 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
   CCGP_LSTORE(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk) && exp != 7 && exp != 8;   // exp 7/8: timing experiments only
+    const bool more = kt + 1 < nk;
     if (more) CCGP_GLOAD();
     const double* Ps = smem + (kt & 1) * STAGE;
     const double* Qs = Ps + kBK * kLdsRow;
@@ -143,7 +144,7 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
       }
     }
     if (more) CCGP_LSTORE((kt + 1) & 1);
-    if (exp != 6 && exp != 8) __syncthreads();
+    __syncthreads();
   }
 #undef CCGP_GLOAD
 #undef CCGP_LSTORE
@@ -171,8 +172,9 @@ constexpr size_t gemm_lds_bytes() {
 
 template <int MODE, int S>
 __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
-  // tile rows j..nt (update) / j+1..nt (trsm); row nt is the thin right-hand-side tile
-  const int ntile = MODE == 0 ? g.nt - g.j + 1 : g.nt - g.j;
+  // tile rows j..nt+ne (update) / j+1..nt+ne (trsm); row nt is the thin right-hand-side tile,
+  // rows above nt are full tiles of extra rows (prediction: r(x_t)')
+  const int ntile = (MODE == 0 ? g.nt - g.j + 1 : g.nt - g.j) + g.ne;
   // block index -> (matrix, tile, strip): strips of a tile adjacent, tiles of a matrix on one
   // XCD group (blocks are dealt round-robin over the 8 XCDs, so index % 8 labels the group and
   // all tiles of one matrix share the Q panel in that XCD's L2)
@@ -185,14 +187,14 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   const int i = g.j + t + (MODE == 0 ? 0 : 1);
   const bool thin = i == g.nt;
   double* Ab = g.A + (size_t)b * g.a_stride;
-  const int ld = g.npad + kTile;
+  const int ld = g.ld;
   const int c0 = strip * (kTile / S);   // first column of this strip inside the tile
 
   const double* P;
   const double* Q;
   int ldP, ldQ, Kdim;
   if (MODE == 0) {
-    P = Ab + (size_t)(g.exp == 1 ? g.j : i) * kTile;
+    P = Ab + (size_t)i * kTile;
     Q = Ab + (size_t)g.j * kTile + c0;
     ldP = ldQ = ld;
     Kdim = g.j * kTile;
@@ -204,14 +206,8 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
     Kdim = kTile;
   }
   double* C = Ab + (size_t)i * kTile + ((size_t)g.j * kTile + c0) * ld;
-  // experiments: de-phase the workgroups that share a CU (they run identical code and would
-  // otherwise reach their per-stage barrier together, idling the MFMA pipe)
-  if (g.exp >= 2) {
-    const int bit = g.exp == 2 ? (L >> 8) & 1 : (g.exp == 3 ? (L >> 9) & 1 : (g.exp == 4 ? (L >> 3) & 1 : (L >> 11) & 1));
-    if (__builtin_amdgcn_readfirstlane(bit)) __builtin_amdgcn_s_sleep(64);
-  }
-  if (thin) gemm_tile<S, true>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE, g.exp);
-  else gemm_tile<S, false>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE, g.exp);
+  if (thin) gemm_tile<S, true>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
+  else gemm_tile<S, false>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
 }
 
 // distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
@@ -246,7 +242,7 @@ static int pick_strips(int tiles) {
 }
 
 static void launch_gemm(hipStream_t s, const GemmArgs& g, int mode, int S) {
-  const int ntile = mode == 0 ? g.nt - g.j + 1 : g.nt - g.j;
+  const int ntile = (mode == 0 ? g.nt - g.j + 1 : g.nt - g.j) + g.ne;
   const int nb8 = round_up(g.nb, 8);
   const dim3 grid(nb8 * ntile * S), block(256);
   if (mode == 0) {
@@ -270,6 +266,7 @@ struct DiagArgs {
   double* logdet_part;  // nb x nt
   int* status;          // indexed from b0
   int j, nt, nb, n;
+  int ld;
 };
 
 // Register-resident: the 256 threads form a 16 x 16 grid (ty = row class, tx = column class)
@@ -284,7 +281,7 @@ __global__ __launch_bounds__(256) void diag_kernel(DiagArgs g) {
   __shared__ double red[4];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, ty = tid & 15, tx = tid >> 4;
-  const int ld = g.npad + kTile;
+  const int ld = g.ld;
   double* C = g.A + (size_t)b * g.a_stride + (size_t)g.j * kTile + (size_t)g.j * kTile * ld;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
@@ -374,17 +371,20 @@ struct RhsArgs {
   size_t a_stride;
   int npad, n;
   const double* y;
+  int ld;
 };
 
 // rows npad..npad+127 of every matrix: y' (zero beyond n), 1' (zero beyond n), zeros
 __global__ void rhs_rows_kernel(RhsArgs g) {
-  const int ld = g.npad + kTile;
+  const int ld = g.ld;
   double* Ab = g.A + (size_t)blockIdx.y * g.a_stride;
   const int c = blockIdx.x;            // one workgroup of 128 threads per column
   const int r = threadIdx.x;
   double v = 0.0;
   if (c < g.n) v = r == 0 ? g.y[c] : (r == 1 ? 1.0 : 0.0);
   Ab[g.npad + r + (size_t)c * ld] = v;
+  // extra tile rows start as zeros (the cross-correlation kernel then fills rows < m, columns < n)
+  for (int e = g.npad + kTile + r; e < ld; e += kTile) Ab[e + (size_t)c * ld] = 0.0;
 }
 
 struct FinishArgs {
@@ -400,6 +400,9 @@ struct FinishArgs {
   double* loglik;
   double* beta;
   const int* status;
+  int ld;
+  double* s11_out;   // nb doubles (1' R^-1 1 in the factor's metric), for the prediction pass
+  double* beta_out;  // nb doubles, chunk-local copy of beta
 };
 
 __device__ inline double block_sum(double v, double* red, int tid) {
@@ -413,7 +416,7 @@ __device__ inline double block_sum(double v, double* red, int tid) {
 __global__ __launch_bounds__(256) void finish_kernel(FinishArgs g) {
   __shared__ double red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int ld = g.npad + kTile;
+  const int ld = g.ld;
   const double* zrow = g.A + (size_t)b * g.a_stride + g.npad;   // z_y[c] = zrow[c*ld], z_1[c] = zrow[1 + c*ld]
   double logdet = 0.0;
   for (int jb = tid; jb < g.nt; jb += 256) logdet += g.logdet_part[(size_t)b * g.nt + jb];
@@ -449,61 +452,109 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs g) {
   if (tid == 0) {
     const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
     if (g.status && g.status[gb] != 0) { ll = kNaN; beta = kNaN; }
-    g.loglik[gb] = ll;
+    if (g.loglik) g.loglik[gb] = ll;
     if (g.beta) g.beta[gb] = beta;
+    if (g.s11_out) g.s11_out[b] = s11;
+    if (g.beta_out) g.beta_out[b] = beta;
   }
+}
+
+// ---- prediction from the extra rows: w_t = L^-1 r(x_t) sits in row npad+128+t ---------------------
+//   mean = beta + (z_y - beta z_1).w ,  var = sigma2 (1 - w.w + (1 - z_1.w)^2 / (z_1.z_1))
+// (predict.post HX:667-670 rewritten in the factor's metric; see small.hip)
+struct PredFinishArgs {
+  const double* A;
+  size_t a_stride;
+  int npad, ld, n, m;
+  const double* s11;
+  const double* beta;
+  const int* status;
+  int b0, S;
+  double sigma2;
+  double* mean;
+  double* var;
+};
+
+__global__ __launch_bounds__(256) void predict_finish_kernel(PredFinishArgs g) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= g.m) return;
+  const double* Ab = g.A + (size_t)b * g.a_stride;
+  const double* zrow = Ab + g.npad;
+  const double* wrow = Ab + g.npad + kTile + t;
+  double ww = 0.0, z1w = 0.0, zyw = 0.0;
+  for (int c = 0; c < g.n; ++c) {
+    const double w = wrow[(size_t)c * g.ld];
+    ww = fma(w, w, ww);
+    z1w = fma(zrow[1 + (size_t)c * g.ld], w, z1w);
+    zyw = fma(zrow[(size_t)c * g.ld], w, zyw);
+  }
+  const double beta = g.beta[b], s11 = g.s11[b];
+  double mean = beta + (zyw - beta * z1w);
+  const double u = 1.0 - z1w;
+  double var = g.sigma2 * (1.0 - ww + u * u / s11);
+  if (g.status && g.status[g.b0 + b] != 0) {
+    mean = var = __longlong_as_double(0x7ff8000000000000LL);
+  }
+  g.mean[(g.b0 + b) + (size_t)t * g.S] = mean;
+  g.var[(g.b0 + b) + (size_t)t * g.S] = var;
 }
 
 }  // namespace
 
-size_t blocked_ws_bytes(int npad, int nb) {
+size_t blocked_ws_bytes(int npad, int nb, int ne) {
   const int nt = npad / kTile;
-  size_t dbl = (size_t)nb * (npad + kTile) * npad + (size_t)nb * nt * kTile * kTile + (size_t)nb * nt + 64;
+  size_t dbl = (size_t)nb * (npad + kTile * (1 + ne)) * npad + (size_t)nb * nt * kTile * kTile +
+               (size_t)nb * (nt + 2) + 64;
   return dbl * sizeof(double);
 }
 
-BlockedWs blocked_carve(void* ws, int npad, int nb) {
+BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
   const int nt = npad / kTile;
   BlockedWs w{};
   w.A = static_cast<double*>(ws);
-  w.a_stride = (size_t)(npad + kTile) * npad;
+  w.ld = npad + kTile * (1 + ne);
+  w.ne = ne;
+  w.a_stride = (size_t)w.ld * npad;
   w.invd = w.A + (size_t)nb * w.a_stride;
-  w.z = w.invd + (size_t)nb * nt * kTile * kTile;  // logdet partials live here (nb x nt)
+  w.z = w.invd + (size_t)nb * nt * kTile * kTile;  // logdet partials (nb x nt), then s11 and beta (nb each)
+  w.fin = w.z + (size_t)nb * nt;
   return w;
 }
 
 // One matrix group's whole sweep, enqueued on stream s.  w is already offset to the group.
 static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n, int d, const double* y,
                           DrawView dv, int b0, int nb, int npad, double sigma2, int mean_mode,
-                          double tau2, BlockedWs w, double* loglik, double* beta, int* status) {
+                          double tau2, BlockedWs w, double* loglik, double* beta, int* status,
+                          const BlockedPredict* pr) {
   const int nt = npad / kTile;
   {
     ScopedTimer t(h, CCGP_T_COV, s);
-    launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2);
-    RhsArgs ra{w.A, w.a_stride, npad, n, y};
+    launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld);
+    RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld};
     hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
+    if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site
+      launch_cov_cross_batched(s, pr->Xtest, pr->m, X, n, d, dv, b0, nb, w.A + npad + kTile, w.a_stride,
+                               w.ld);
   }
   GemmArgs g{};
   g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
-  g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb;
+  g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb; g.ld = w.ld; g.ne = w.ne;
   DiagArgs dg{};
   dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
   dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
-  dg.nb = nb; dg.n = n;
-  static int force_s = -1, exp_mode = 0;
+  dg.nb = nb; dg.n = n; dg.ld = w.ld;
+  static int force_s = -1;   // CCGP_STRIPS=1|2|4 pins the strip count (profiling only)
   if (force_s < 0) {
     const char* e = getenv("CCGP_STRIPS");
     force_s = e ? atoi(e) : 0;
-    const char* x = getenv("CCGP_EXP");
-    exp_mode = x ? atoi(x) : 0;
   }
-  g.exp = exp_mode;
   for (int j = 0; j < nt; ++j) {
     g.j = j;
     if (j > 0) {
       ScopedTimer t(h, CCGP_T_UPDATE, s);
       g.mode = 0;
-      launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8) * (nt - j + 1)));
+      launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8) * (nt - j + 1 + w.ne)));
     }
     {
       ScopedTimer t(h, CCGP_T_DIAG, s);
@@ -521,14 +572,20 @@ static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n,
     FinishArgs fa{};
     fa.A = w.A; fa.a_stride = w.a_stride; fa.npad = npad; fa.logdet_part = w.z; fa.params = dv.params;
     fa.ldp = dv.ldp; fa.K = dv.K; fa.b0 = b0; fa.nt = nt; fa.n = n; fa.sigma2 = sigma2;
-    fa.mode = mean_mode; fa.loglik = loglik; fa.beta = beta; fa.status = status;
+    fa.mode = mean_mode; fa.loglik = loglik; fa.beta = beta; fa.status = status; fa.ld = w.ld;
+    fa.s11_out = w.fin; fa.beta_out = w.fin + nb;
     hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, s, fa);
+    if (pr) {
+      PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, pr->m, w.fin, w.fin + nb, status, b0, pr->S,
+                        sigma2, pr->mean, pr->var};
+      hipLaunchKernelGGL(predict_finish_kernel, dim3((pr->m + 255) / 256, nb), dim3(256), 0, s, pa);
+    }
   }
 }
 
 void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
-                    BlockedWs w, double* loglik, double* beta, int* status) {
+                    BlockedWs w, double* loglik, double* beta, int* status, const BlockedPredict* pr) {
   const int nt = npad / kTile;
   static bool attr_set = false;
   if (!attr_set) {
@@ -546,7 +603,7 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   if (ng < 1) ng = 1;
   if (ng == 1) {
     blocked_group(h, h->stream, X, n, d, y, dv, b0, nb, npad, sigma2, mean_mode, tau2, w, loglik, beta,
-                  status);
+                  status, pr);
     return;
   }
   (void)hipEventRecord(h->fork, h->stream);
@@ -559,8 +616,9 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
     wg.A = w.A + (size_t)m0 * w.a_stride;
     wg.invd = w.invd + (size_t)m0 * nt * kTile * kTile;
     wg.z = w.z + (size_t)m0 * nt;
+    wg.fin = w.fin + (size_t)2 * m0;   // (s11, beta) pairs are addressed as fin[0..cnt) and fin[cnt..2cnt)
     blocked_group(h, s, X, n, d, y, dv, b0 + m0, cnt, npad, sigma2, mean_mode, tau2, wg, loglik, beta,
-                  status);
+                  status, pr);
     (void)hipEventRecord(h->gjoin[gidx], s);
     (void)hipStreamWaitEvent(h->stream, h->gjoin[gidx], 0);
   }

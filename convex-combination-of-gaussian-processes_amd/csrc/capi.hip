@@ -82,8 +82,8 @@ bool bad_shape(int n, int d, int K) {
 }
 
 // blocked-path chunk size (matrices per pass) under the workspace limit
-int blocked_chunk(const ccgp_handle* h, int npad, int B) {
-  size_t per = blocked_ws_bytes(npad, 1);
+int blocked_chunk(const ccgp_handle* h, int npad, int B, int ne = 0) {
+  size_t per = blocked_ws_bytes(npad, 1, ne);
   size_t nb = h->ws_limit / per;
   if (nb < 1) nb = 1;
   if (nb > (size_t)B) nb = B;
@@ -113,12 +113,12 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
   }
   const int npad = round_up(n, kTile);
   const int nbc = blocked_chunk(h, npad, B);
-  int rc = ensure_ws(h, blocked_ws_bytes(npad, nbc));
+  int rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, 0));
   if (rc) return rc;
   CCGP_HIP(hipMemsetAsync(d_status, 0, sizeof(int) * (size_t)B, h->stream));
   for (int b0 = 0; b0 < B; b0 += nbc) {
     const int nb = std::min(nbc, B - b0);
-    BlockedWs w = blocked_carve(h->ws, npad, nb);
+    BlockedWs w = blocked_carve(h->ws, npad, nb, 0);
     blocked_loglik(h, dX, n, d, dy, dv, b0, nb, npad, sigma2, mean_mode, tau2, w, d_loglik, d_beta,
                    d_status);
   }
@@ -308,7 +308,8 @@ int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m) {
   CCGP_HIP(hipSetDevice(h->device));
   if (n > kSmallMaxN) {
     const int npad = round_up(n, kTile);
-    int rc = ensure_ws(h, blocked_ws_bytes(npad, blocked_chunk(h, npad, B)));
+    const int ne = (m + kTile - 1) / kTile;
+    int rc = ensure_ws(h, blocked_ws_bytes(npad, blocked_chunk(h, npad, B, ne), ne));
     if (rc) return rc;
   }
   const int P = K + K * d;
@@ -754,10 +755,31 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || S < 1 || m < 1 || !dX || !dy || !dparams || !dXtest || !d_mean || !d_var)
     return fail(h, CCGP_EINVAL, "ccgp_predict_batch: bad argument");
-  if (n > kSmallMaxN)
-    return fail(h, CCGP_EUNSUPPORTED, "ccgp_predict_batch: n > 128 not implemented yet");
   CCGP_HIP(hipSetDevice(h->device));
   DrawView dv{dparams, S, K, d};
+  if (n > kSmallMaxN) {
+    // blocked path: the m cross-correlation rows ride along as extra tile rows of the sweep
+    const int npad = round_up(n, kTile), ne = (m + kTile - 1) / kTile;
+    const int nbc = blocked_chunk(h, npad, S, ne);
+    size_t extra = Carver::al(sizeof(double) * (size_t)S) * 2 + Carver::al(sizeof(int) * (size_t)S);
+    int rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, ne) + extra);
+    if (rc) return rc;
+    // scratch for outputs the caller did not ask for lives behind the matrices
+    Carver tail(static_cast<char*>(h->ws) + blocked_ws_bytes(npad, nbc, ne));
+    double* ll = tail.take<double>(S);
+    double* bt = d_beta ? d_beta : tail.take<double>(S);
+    int* st = d_status ? d_status : tail.take<int>(S);
+    CCGP_HIP(hipMemsetAsync(st, 0, sizeof(int) * (size_t)S, h->stream));
+    BlockedPredict pr{dXtest, m, S, d_mean, d_var};
+    for (int b0 = 0; b0 < S; b0 += nbc) {
+      const int nb = std::min(nbc, S - b0);
+      BlockedWs w = blocked_carve(h->ws, npad, nb, ne);
+      blocked_loglik(h, dX, n, d, dy, dv, b0, nb, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, ll, bt, st,
+                     &pr);
+    }
+    CCGP_HIP(hipGetLastError());
+    return CCGP_OK;
+  }
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     launch_small_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,

@@ -72,7 +72,9 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
 // the padding), z in [0, nb).  scale/shift: mode 0 -> (1, 0); mode 1 -> (sigma2*sum w^2, tau2).
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2);
+                      double tau2, int ld);
+void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const double* X, int n, int d,
+                              DrawView dv, int b0, int nb, double* Abase, size_t batch_stride, int ldo);
 
 // ---- small.hip -----------------------------------------------------------------------
 // Fused evaluator: one workgroup per draw (and per test-point chunk when m > 0).
@@ -101,18 +103,29 @@ void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const
 
 // ---- blocked.hip ---------------------------------------------------------------------
 struct BlockedWs {
-  double* A;        // nb x npad x npad (lower tiles used)
+  double* A;        // nb matrices of ld x npad (lower tiles + right-hand-side / extra tile rows)
   double* invd;     // nb x nt x 128 x 128 inverses of the diagonal blocks
-  double* z;        // nb x 2 x npad forward-solve vectors (y, 1)
+  double* z;        // nb x nt log-det partials
+  double* fin;      // nb x 2: s11 = 1'R^-1 1 and beta per matrix (prediction pass)
   size_t a_stride;  // elements between consecutive matrices
+  int ld;           // npad + 128 * (1 + ne)
+  int ne;           // extra full tile rows (ceil(m / 128) for prediction, else 0)
 };
-size_t blocked_ws_bytes(int npad, int nb);
-BlockedWs blocked_carve(void* ws, int npad, int nb);
+// optional prediction request riding on a blocked sweep (a10 + a11 for n > 128)
+struct BlockedPredict {
+  const double* Xtest;  // m x d, device
+  int m, S;
+  double* mean;         // S x m column-major, device
+  double* var;
+};
+size_t blocked_ws_bytes(int npad, int nb, int ne);
+BlockedWs blocked_carve(void* ws, int npad, int nb, int ne);
 // factorise nb matrices in place and finish the likelihood; loglik/beta/status are
 // indexed from draw b0.
 void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
-                    BlockedWs w, double* loglik, double* beta, int* status);
+                    BlockedWs w, double* loglik, double* beta, int* status,
+                    const BlockedPredict* pr = nullptr);
 
 // ---- special.cpp ---------------------------------------------------------------------
 void halton_base2(int N, double* out);

@@ -134,14 +134,26 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
 
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2) {
+                      double tau2, int ld) {
   CovArgs a{};
   a.A = X; a.Bm = X; a.m = n; a.n = n; a.d = d;
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = b0;
-  a.out = Abase; a.batch_stride = batch_stride; a.ldo = npad + kTile; a.mode = mean_mode;
+  a.out = Abase; a.batch_stride = batch_stride; a.ldo = ld; a.mode = mean_mode;
   a.sigma2 = sigma2; a.tau2 = tau2; a.lower_tiles = 1; a.npad = npad;
   int nt64 = npad / 64;
   dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
+  hipLaunchKernelGGL(cov_kernel, grid, dim3(256), cov_lds(d, dv.K), s, a);
+}
+
+// Batched cross-correlation rows for the blocked prediction path: for draw b0+z the m x n block
+// out[t + i*ldo] = R_mixed(x_t, x_i) (normalised, no scale/shift) at Abase + z*batch_stride.
+void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const double* X, int n, int d,
+                              DrawView dv, int b0, int nb, double* Abase, size_t batch_stride, int ldo) {
+  CovArgs a{};
+  a.A = Xtest; a.Bm = X; a.m = m; a.n = n; a.d = d;
+  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = b0;
+  a.out = Abase; a.batch_stride = batch_stride; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
+  dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, nb);
   hipLaunchKernelGGL(cov_kernel, grid, dim3(256), cov_lds(d, dv.K), s, a);
 }
 

@@ -277,6 +277,21 @@ def test_blocked_path_vs_oracle(handle, n, d, K, mode):
         assert beta[b] == pytest.approx(wb, rel=1e-8, abs=1e-11)
 
 
+@pytest.mark.parametrize("n,m", [(300, 150), (200, 1), (520, 260)])
+def test_blocked_path_prediction(handle, n, m):
+    """a10 + a11 for n > 128: the cross-correlation rows ride along as extra tile rows."""
+    X, y = synthetic_design(n, 3, seed=n + 1)
+    Xt = np.random.default_rng(n).random((m, 3))
+    draws = [(0.7, 3.0, 40.0), (0.6, 6.0, 90.0), (0.8, 2.0, 60.0)]
+    P = np.stack([orc.params_from_iso(p, t1, t2, 3) for p, t1, t2 in draws])
+    mean, var, beta, st = handle.predict_batch(X, y, 2, P, Xt, 1.7)
+    assert not st.any()
+    wm, wv, wb = orc.predict_table(X, y, draws, Xt, 1.7)
+    np.testing.assert_allclose(beta, wb, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(mean, wm, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(var, wv, rtol=1e-7, atol=1e-9 * 1.7)
+
+
 def test_small_and_blocked_agree_across_the_cutover(handle):
     """n = 128 runs the fused kernel, n = 129 the blocked one: appending one far-away,
     nearly independent point must change the likelihood by exactly its own marginal term."""

@@ -148,7 +148,8 @@ int ccgp_qigamma(const double* p, int N, double alpha, double beta, double* out)
 /* ---- a10/a11: factors HX:604-613, predict.post HX:655-673 / ANI:604-623 --------------
  * ccgp_predict_batch recomputes, per draw, what Metro caches (R.Inv, beta; HX:515-525)
  * and returns the S x m tables mean[s + t*S], var[s + t*S] that prediction() averages
- * (HX:688-693).  out_beta (S) and status (S) may be NULL. */
+ * (HX:688-693).  out_beta (S) and status (S) may be NULL.  Any n: n <= 128 runs the fused
+ * in-LDS evaluator, larger n appends the m cross-correlation rows to the blocked sweep. */
 int ccgp_predict_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
                        const double* params, int S, const double* Xtest, int m, double sigma2,
                        double* out_mean, double* out_var, double* out_beta, int* status);

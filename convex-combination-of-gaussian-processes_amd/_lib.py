@@ -15,7 +15,8 @@ class LibraryMissing(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "csrc", "libccgp.so")
+    """In-tree build product; CCGP_LIB overrides it (A/B runs of differently built libraries)."""
+    return os.environ.get("CCGP_LIB") or os.path.join(_HERE, "csrc", "libccgp.so")
 
 
 def load_library() -> ctypes.CDLL:

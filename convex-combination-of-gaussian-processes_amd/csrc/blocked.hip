@@ -30,7 +30,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kBK = 16;              // k-depth of one LDS stage
-constexpr int kLdsRow = kTile + 16;  // padded row (doubles): 1152 B, conflict-free ds_read_b64
 
 struct GemmArgs {
   double* A;
@@ -45,27 +44,34 @@ struct GemmArgs {
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
-// (128 / S) columns per workgroup, K-loop over 16-deep LDS stages (double buffered,
-// register-staged global loads issued one stage ahead).
+// (128 / S) columns per workgroup, K-loop over 16-deep double-buffered LDS stages.
 //   S = 1: 2 x 2 waves of 64 x 64      S = 2: 2 x 2 waves of 64 x 32      S = 4: 4 x 1 waves of 32 x 32
 // S > 1 exists for wave quantisation: a launch whose workgroup count is 512 m + (a few) would
 // leave the chip mostly idle for a whole tile time; cutting every tile into S column strips
 // shortens that tail S-fold at the price of re-reading the P panel S times through L2.
 // THIN = the right-hand-side tile row: only its first 16 rows carry data, so the waves split
 // the strip's columns between them (16 rows x 32 / 16 / 16 columns per wave for S = 1 / 2 / 4).
+//
+// Staging is LDS-DMA: the next stage is filled by global_load_lds (16 B per lane, one
+// wave-instruction = 1 KiB landing linearly in LDS) while the MFMAs of the current stage run,
+// so there is no VGPR staging and no ds_write pass (measured 3 % faster than register staging,
+// profiles/r01c_strip_selection.md).  Because the DMA destination is lane-linear, the LDS image
+// is UNPADDED ([k][128] / [k][CW] doubles) and bank conflicts are removed by an XOR swizzle
+// instead: the 16-row block index of column k is XORed with (k & 1), applied on the per-lane
+// SOURCE address and again on the fragment read (both sides or neither).
 template <int S, bool THIN>
 __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
-                                          int ldQ, int Kdim, double* C, int ld, int mode) {
-  constexpr int CW = kTile / S;                         // columns handled by this workgroup
-  constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);   // 16-wide column sub-tiles per wave
-  constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);       // 16-high row sub-tiles per wave
-  constexpr int QROW = CW + 16;                         // padded LDS row of the Q stage (doubles)
-  constexpr int STAGE = kBK * kLdsRow + kBK * QROW;     // doubles per stage
-  constexpr int QLD = CW / 32;                          // double2 loads of Q per thread per stage
+                                               int ldQ, int Kdim, double* C, int ld, int mode) {
+  constexpr int CW = kTile / S;
+  constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);
+  constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);
+  constexpr int STAGE = kBK * kTile + kBK * CW;        // doubles per stage, unpadded
+  constexpr int CPI = kTile / CW;                      // Q columns covered by one wave-instruction (1, 2, 4)
+  constexpr int QI = kBK / CPI / 4;                    // Q wave-instructions per wave per stage (4, 2, 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = THIN ? 0 : (S == 4 ? wave * 32 : (wave >> 1) * 64);
   const int col0 = THIN ? wave * NX * 16 : (S == 4 ? 0 : (wave & 1) * (S == 1 ? 64 : 32));
-  const bool active = !THIN || col0 < CW;               // S = 4 thin strips occupy two waves only
+  const bool active = !THIN || col0 < CW;
   const int l15 = lane & 15, l4 = lane >> 4;
 
   d4 acc[NX][NY];
@@ -74,67 +80,50 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
 #pragma unroll
     for (int y = 0; y < NY; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
 
-  // staging (plain unrolled code on purpose: arrays captured by a lambda end up in scratch).
-  // P: 128 rows x 16 k per stage = 4 x 16 B per thread; a wave covers one whole 1 KiB column.
-  // Q: CW rows x 16 k per stage = QLD x 16 B per thread; thread t -> k = t / (CW/2), rows 2 (t % (CW/2)).
-  const int r2 = lane * 2;
-  const double* pP = P + r2 + (size_t)wave * ldP;
+  // per-lane source rows.  P: wave w issues columns k = w + 4q (parity = w & 1, fixed per wave).
+  const int psrc = ((((lane >> 3) ^ (wave & 1)) << 4) + ((lane & 7) << 1));
+  const double* pP = P + psrc + (size_t)wave * ldP;
   const size_t stepP = (size_t)4 * ldP;
-  constexpr int QT = CW / 2;                 // threads per Q column
-  constexpr int QK = 256 / QT;               // Q columns covered per pass
-  const int qrow2 = (tid % QT) * 2, qk = tid / QT;
-  const double* pQ = Q + qrow2 + (size_t)qk * ldQ;
-  const size_t stepQ = (size_t)QK * ldQ;
-  // (scalars, not arrays: hipcc keeps staging ARRAYS that live across the `if (more)` in scratch)
-  double2 pr0, pr1, pr2, pr3, qr0, qr1, qr2, qr3;
-  qr1 = qr2 = qr3 = double2{0.0, 0.0};
-#define CCGP_GLOAD()                                                              \
-  do {                                                                            \
-    pr0 = *reinterpret_cast<const double2*>(pP);                                  \
-    pr1 = *reinterpret_cast<const double2*>(pP + stepP);                          \
-    pr2 = *reinterpret_cast<const double2*>(pP + 2 * stepP);                      \
-    pr3 = *reinterpret_cast<const double2*>(pP + 3 * stepP);                      \
-    qr0 = *reinterpret_cast<const double2*>(pQ);                                  \
-    if constexpr (QLD > 1) qr1 = *reinterpret_cast<const double2*>(pQ + stepQ);   \
-    if constexpr (QLD > 2) {                                                      \
-      qr2 = *reinterpret_cast<const double2*>(pQ + 2 * stepQ);                    \
-      qr3 = *reinterpret_cast<const double2*>(pQ + 3 * stepQ);                    \
-    }                                                                             \
-    pP += 4 * stepP;                                                              \
-    pQ += QLD * stepQ;                                                            \
-  } while (0)
-#define CCGP_LSTORE(stage)                                                        \
-  do {                                                                            \
-    double* Ps_ = smem + (stage) * STAGE + wave * kLdsRow + r2;                   \
-    double* Qs_ = smem + (stage) * STAGE + kBK * kLdsRow + qk * QROW + qrow2;     \
-    *reinterpret_cast<double2*>(Ps_) = pr0;                                       \
-    *reinterpret_cast<double2*>(Ps_ + 4 * kLdsRow) = pr1;                         \
-    *reinterpret_cast<double2*>(Ps_ + 8 * kLdsRow) = pr2;                         \
-    *reinterpret_cast<double2*>(Ps_ + 12 * kLdsRow) = pr3;                        \
-    *reinterpret_cast<double2*>(Qs_) = qr0;                                       \
-    if constexpr (QLD > 1) *reinterpret_cast<double2*>(Qs_ + QK * QROW) = qr1;    \
-    if constexpr (QLD > 2) {                                                      \
-      *reinterpret_cast<double2*>(Qs_ + 2 * QK * QROW) = qr2;                     \
-      *reinterpret_cast<double2*>(Qs_ + 3 * QK * QROW) = qr3;                     \
-    }                                                                             \
-  } while (0)
+  // Q: instruction u = w + 4q covers columns CPI*u .. CPI*u + CPI-1; lane -> column CPI*u + lane / (64/CPI)
+  constexpr int LPC = 64 / CPI;                        // lanes per Q column
+  const int qcol_in = lane / LPC, ql = lane % LPC;
+  const int qpar = CPI == 1 ? (wave & 1) : (qcol_in & 1);
+  const int qsrc = ((((ql >> 3) ^ qpar) << 4) + ((ql & 7) << 1));
+  const double* pQ = Q + qsrc + (size_t)(CPI * wave + qcol_in) * ldQ;
+  const size_t stepQ = (size_t)(4 * CPI) * ldQ;
+
+  auto issue = [&](int stage) {
+    double* Ps_ = smem + stage * STAGE + wave * kTile;          // wave-uniform LDS bases
+    double* Qs_ = smem + stage * STAGE + kBK * kTile + wave * kTile;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pP + q * stepP),
+                                       (__attribute__((address_space(3))) void*)(Ps_ + 4 * q * kTile), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < QI; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pQ + q * stepQ),
+                                       (__attribute__((address_space(3))) void*)(Qs_ + 4 * q * kTile), 16, 0, 0);
+    pP += 4 * stepP;
+    pQ += QI * stepQ;
+  };
 
   const int nk = Kdim / kBK;
-  CCGP_GLOAD();
-  CCGP_LSTORE(0);
-  __syncthreads();
+  issue(0);
+  __syncthreads();   // drains the DMA (vmcnt(0)) and publishes it
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) CCGP_GLOAD();
+    if (kt + 1 < nk) issue((kt + 1) & 1);
     const double* Ps = smem + (kt & 1) * STAGE;
-    const double* Qs = Ps + kBK * kLdsRow;
+    const double* Qs = Ps + kBK * kTile;
+    const int sw = l4 & 1;   // k parity of this lane's fragment element (k = 4 kk + l4)
 #pragma unroll
     for (int kk = 0; kk < kBK / 4; ++kk) {
       double pf[NY], qf[NX];
 #pragma unroll
-      for (int y = 0; y < NY; ++y) pf[y] = Ps[(kk * 4 + l4) * kLdsRow + row0 + y * 16 + l15];
+      for (int y = 0; y < NY; ++y)
+        pf[y] = Ps[(kk * 4 + l4) * kTile + ((((row0 >> 4) + y) ^ sw) << 4) + l15];
 #pragma unroll
-      for (int x = 0; x < NX; ++x) qf[x] = Qs[(kk * 4 + l4) * QROW + col0 + x * 16 + l15];
+      for (int x = 0; x < NX; ++x)
+        qf[x] = Qs[(kk * 4 + l4) * CW + ((((col0 >> 4) + x) ^ sw) << 4) + l15];
       if (active) {
 #pragma unroll
         for (int x = 0; x < NX; ++x)
@@ -143,13 +132,9 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
             acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[x], pf[y], acc[x][y], 0, 0, 0);
       }
     }
-    if (more) CCGP_LSTORE((kt + 1) & 1);
     __syncthreads();
   }
-#undef CCGP_GLOAD
-#undef CCGP_LSTORE
 
-  // epilogue: accumulator register r of sub-tile (x, y) is C[row0 + 16y + l15][col0 + 16x + l4 + 4r]
   if (!active) return;
 #pragma unroll
   for (int x = 0; x < NX; ++x)
@@ -167,7 +152,7 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
 
 template <int S>
 constexpr size_t gemm_lds_bytes() {
-  return sizeof(double) * 2 * (kBK * kLdsRow + kBK * (kTile / S + 16));
+  return sizeof(double) * 2 * (kBK * kTile + kBK * (kTile / S));   // two unpadded stages
 }
 
 template <int MODE, int S>

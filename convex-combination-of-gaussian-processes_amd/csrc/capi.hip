@@ -99,10 +99,12 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
     return fail(h, CCGP_EINVAL, "ccgp_loglik_batch: unknown mean_mode");
   if (B == 0) return CCGP_OK;
   DrawView dv{dparams, B, K, d};
-  if (n <= kSmallMaxN) {
+  static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
+  const bool reg_ok = small_reg_supported(n, d) && !force_lds;
+  const bool lds_ok = n <= kSmallMaxN && small_lds_bytes(n, d, 0) <= (size_t)kLdsBytes - 64;
+  if (reg_ok || lds_ok) {   // otherwise (n > 128, or d too large for LDS) the blocked path takes it
     ScopedTimer t(h, CCGP_T_FUSED);
-    static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
-    if (small_reg_supported(n, d) && !force_lds)
+    if (reg_ok)
       launch_small_reg_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
                               d_status);
     else

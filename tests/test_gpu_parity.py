@@ -106,6 +106,49 @@ def test_loglik_batch_qian_vs_oracle(handle, mode):
         assert beta[b] == pytest.approx(wb, rel=1e-10, abs=1e-13)
 
 
+@pytest.mark.parametrize("n", [5, 8, 9, 31, 48, 63, 64, 65, 80, 97, 112, 127, 128])
+def test_fused_evaluator_size_sweep(handle, n):
+    """Every template instance of the register-resident evaluator (G = 8: n <= 64, G = 16: n <= 128),
+    K = 1, 2 and 3 components, both likelihood modes."""
+    X, y = synthetic_design(n, 3, seed=100 + n)
+    rng = np.random.default_rng(n)
+    for K in (1, 2, 3):
+        B = 3
+        P = np.empty((B, K + 3 * K))
+        for b in range(B):
+            w = rng.dirichlet(np.ones(K)) if K > 1 else np.array([1.0])
+            th = np.exp(rng.uniform(np.log(2.0), np.log(60.0), size=(K, 3)))
+            th[-1] = np.maximum(th[-1], 30.0)
+            P[b] = np.concatenate([w, th.ravel()])
+        for mode in (0, 1):
+            ll, beta, st = handle.loglik_batch(X, y, K, P, 0.9, mode, 25.0)
+            assert not st.any()
+            for b in range(B):
+                w, Th = orc.unpack_params(P[b], K, 3)
+                wl, wb = orc.loglik_general(X, y, w, Th, 0.9, mode, 25.0)
+                assert ll[b] == pytest.approx(wl, rel=1e-9, abs=1e-9)
+                assert beta[b] == pytest.approx(wb, rel=1e-8, abs=1e-11)
+
+
+def test_large_input_dimension_routes_to_a_path_that_fits(handle):
+    """d = 40 at n = 120 does not fit the LDS budget of the fused kernels' design copy for every
+    variant; whichever path runs, the answer is the oracle's."""
+    rng = np.random.default_rng(5)
+    X = rng.random((120, 40))
+    y = np.sin(X.sum(axis=1))
+    P = np.concatenate([[0.6, 0.4], np.full(40, 0.05), np.full(40, 2.0)])[None]
+    ll, beta, st = handle.loglik_batch(X, y, 2, P, 1.0, 0, 0.0)
+    w, Th = orc.unpack_params(P[0], 2, 40)
+    wl, wb = orc.loglik_general(X, y, w, Th, 1.0)
+    assert st[0] == 0 and ll[0] == pytest.approx(wl, rel=1e-9) and beta[0] == pytest.approx(wb, rel=1e-8)
+    X2 = rng.random((128, 64))
+    P2 = np.concatenate([[0.6, 0.4], np.full(64, 0.03), np.full(64, 1.0)])[None]
+    y2 = np.cos(X2.sum(axis=1))
+    ll2, _, st2 = handle.loglik_batch(X2, y2, 2, P2, 1.0, 1, 4.0)
+    w2, Th2 = orc.unpack_params(P2[0], 2, 64)
+    assert st2[0] == 0 and ll2[0] == pytest.approx(orc.loglik_general(X2, y2, w2, Th2, 1.0, 1, 4.0)[0], rel=1e-9)
+
+
 def test_logpost_golden_every_script(handle):
     from ccgp_amd.rsurface import CombinedGP
     D, y, _, _ = load_qian()

@@ -540,8 +540,8 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || B < 1 || !X || !y || !params || !out_grad)
     return fail(h, CCGP_EINVAL, "ccgp_loglik_grad_batch: bad argument");
-  if (n > kSmallMaxN)
-    return fail(h, CCGP_EUNSUPPORTED, "ccgp_loglik_grad_batch: n > 128 not implemented yet");
+  if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)
+    return fail(h, CCGP_EUNSUPPORTED, "ccgp_loglik_grad_batch: n > 128 (or a design too wide for LDS) not implemented yet");
   CCGP_HIP(hipSetDevice(h->device));
   const int P = K + K * d;
   const int nch = small_grad_chunks(n, d);
@@ -622,8 +622,8 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
                              &ll, &beta, &st);
   if (rc < 0) return rc;
   if (out_Rinv) {
-    if (n > kSmallMaxN)
-      return fail(h, CCGP_EUNSUPPORTED, "ccgp_logpost: R.Inv output for n > 128 not implemented yet");
+    if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)
+      return fail(h, CCGP_EUNSUPPORTED, "ccgp_logpost: R.Inv output for n > 128 (or a design too wide for LDS) not implemented yet");
     size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * P) +
                   Carver::al(sizeof(double) * (size_t)n * n) + 256;
     int rc2 = ensure_stage(h, need);
@@ -759,7 +759,7 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
     return fail(h, CCGP_EINVAL, "ccgp_predict_batch: bad argument");
   CCGP_HIP(hipSetDevice(h->device));
   DrawView dv{dparams, S, K, d};
-  if (n > kSmallMaxN) {
+  if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
     // blocked path: the m cross-correlation rows ride along as extra tile rows of the sweep
     const int npad = round_up(n, kTile), ne = (m + kTile - 1) / kTile;
     const int nbc = blocked_chunk(h, npad, S, ne);

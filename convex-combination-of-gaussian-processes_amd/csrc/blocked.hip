@@ -40,6 +40,7 @@ struct GemmArgs {
   int j, nt, nb;
   int ld;    // leading dimension = npad + 128 (right-hand-side tile row) + 128 * ne
   int ne;    // extra full tile rows below the right-hand-side row (cross-correlation rows)
+  int extra_lower;  // 1: the extra rows are the identity (block row te is zero left of block column te)
   int mode;  // 0: update, 1: trsm
 };
 
@@ -60,21 +61,34 @@ struct GemmArgs {
 // instead: the 16-row block index of column k is XORed with (k & 1), applied on the per-lane
 // SOURCE address and again on the fragment read (both sides or neither).
 template <int S, bool THIN>
-__device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
-                                               int ldQ, int Kdim, double* C, int ld, int mode) {
-  constexpr int CW = kTile / S;
-  constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);
-  constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);
+struct TileGeom {
+  static constexpr int CW = kTile / S;                                       // columns per workgroup
+  static constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);      // 16-wide column sub-tiles per wave
+  static constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);                     // 16-high row sub-tiles per wave
+  __device__ static int row0(int wave) { return THIN ? 0 : (S == 4 ? wave * 32 : (wave >> 1) * 64); }
+  __device__ static int col0(int wave) {
+    return THIN ? wave * NX * 16 : (S == 4 ? 0 : (wave & 1) * (S == 1 ? 64 : 32));
+  }
+};
+
+// acc[x][y] += (Q strip)(P tile)' over Kdim: accumulator register r of sub-tile (x, y) is element
+// (row0 + 16y + lane&15, col0 + 16x + (lane>>4) + 4r) of the 128 x CW output.
+template <int S, bool THIN>
+__device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, int ldP, const double* Q,
+                                                int ldQ, int Kdim,
+                                                d4 (&acc)[TileGeom<S, THIN>::NX][TileGeom<S, THIN>::NY]) {
+  constexpr int CW = TileGeom<S, THIN>::CW;
+  constexpr int NX = TileGeom<S, THIN>::NX;
+  constexpr int NY = TileGeom<S, THIN>::NY;
   constexpr int STAGE = kBK * kTile + kBK * CW;        // doubles per stage, unpadded
   constexpr int CPI = kTile / CW;                      // Q columns covered by one wave-instruction (1, 2, 4)
   constexpr int QI = kBK / CPI / 4;                    // Q wave-instructions per wave per stage (4, 2, 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = THIN ? 0 : (S == 4 ? wave * 32 : (wave >> 1) * 64);
-  const int col0 = THIN ? wave * NX * 16 : (S == 4 ? 0 : (wave & 1) * (S == 1 ? 64 : 32));
+  const int row0 = TileGeom<S, THIN>::row0(wave);
+  const int col0 = TileGeom<S, THIN>::col0(wave);
   const bool active = !THIN || col0 < CW;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  d4 acc[NX][NY];
 #pragma unroll
   for (int x = 0; x < NX; ++x)
 #pragma unroll
@@ -135,7 +149,20 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
     __syncthreads();
   }
 
-  if (!active) return;
+}
+
+// C = C - acc (mode 0) or C = acc (mode 1) for one strip.
+template <int S, bool THIN>
+__device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
+                                          int ldQ, int Kdim, double* C, int ld, int mode) {
+  constexpr int NX = TileGeom<S, THIN>::NX;
+  constexpr int NY = TileGeom<S, THIN>::NY;
+  d4 acc[NX][NY];
+  gemm_accumulate<S, THIN>(smem, P, ldP, Q, ldQ, Kdim, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = TileGeom<S, THIN>::row0(wave), col0 = TileGeom<S, THIN>::col0(wave);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  if (THIN && col0 >= TileGeom<S, THIN>::CW) return;
 #pragma unroll
   for (int x = 0; x < NX; ++x)
 #pragma unroll
@@ -175,14 +202,22 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   const int ld = g.ld;
   const int c0 = strip * (kTile / S);   // first column of this strip inside the tile
 
+  // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
+  // zero (skipped) and the update's k-sum starts at te
+  int k0 = 0;
+  if (g.extra_lower && i > g.nt) {
+    const int te = i - g.nt - 1;
+    if (g.j < te || (MODE == 0 && g.j == te)) return;
+    k0 = te * kTile;
+  }
   const double* P;
   const double* Q;
   int ldP, ldQ, Kdim;
   if (MODE == 0) {
-    P = Ab + (size_t)i * kTile;
-    Q = Ab + (size_t)g.j * kTile + c0;
+    P = Ab + (size_t)i * kTile + (size_t)k0 * ld;
+    Q = Ab + (size_t)g.j * kTile + c0 + (size_t)k0 * ld;
     ldP = ldQ = ld;
-    Kdim = g.j * kTile;
+    Kdim = g.j * kTile - k0;
   } else {
     P = Ab + (size_t)i * kTile + (size_t)g.j * kTile * ld;
     Q = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile + c0;
@@ -357,6 +392,7 @@ struct RhsArgs {
   int npad, n;
   const double* y;
   int ld;
+  int identity;   // extra rows = identity (inverse / gradient) instead of zeros (prediction)
 };
 
 // rows npad..npad+127 of every matrix: y' (zero beyond n), 1' (zero beyond n), zeros
@@ -369,7 +405,8 @@ __global__ void rhs_rows_kernel(RhsArgs g) {
   if (c < g.n) v = r == 0 ? g.y[c] : (r == 1 ? 1.0 : 0.0);
   Ab[g.npad + r + (size_t)c * ld] = v;
   // extra tile rows start as zeros (the cross-correlation kernel then fills rows < m, columns < n)
-  for (int e = g.npad + kTile + r; e < ld; e += kTile) Ab[e + (size_t)c * ld] = 0.0;
+  for (int e = g.npad + kTile + r; e < ld; e += kTile)
+    Ab[e + (size_t)c * ld] = (g.identity && e - (g.npad + kTile) == c) ? 1.0 : 0.0;
 }
 
 struct FinishArgs {
@@ -485,6 +522,215 @@ __global__ __launch_bounds__(256) void predict_finish_kernel(PredFinishArgs g) {
   g.var[(g.b0 + b) + (size_t)t * g.S] = var;
 }
 
+// ---- explicit inverse and gradient from the identity rows ----------------------------------------
+// After a sweep with the identity as extra rows, row t of the extra block is Z[t][c] = (L^-1)[c][t]
+// (zero for c < t), i.e. Z = L^-T, and  R^-1 = Z Z'.
+struct AlphaArgs {
+  const double* A;
+  size_t a_stride;
+  int npad, ld, n;
+  const double* beta;   // chunk-local (fin + nb)
+  double* alpha;        // nb x npad:  R^-1 (y - beta 1) = Z (z_y - beta z_1)
+};
+
+__global__ __launch_bounds__(256) void alpha_kernel(AlphaArgs g) {
+  const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= g.npad) return;
+  const double* Ab = g.A + (size_t)b * g.a_stride;
+  const double* zrow = Ab + g.npad;
+  const double* Zrow = Ab + g.npad + kTile + a;
+  const double beta = g.beta[b];
+  double s = 0.0;
+  if (a < g.n)
+    for (int c = a; c < g.n; ++c)
+      s = fma(Zrow[(size_t)c * g.ld], zrow[(size_t)c * g.ld] - beta * zrow[1 + (size_t)c * g.ld], s);
+  g.alpha[(size_t)b * g.npad + a] = s;
+}
+
+struct RinvArgs {
+  const double* A;
+  size_t a_stride;
+  int npad, ld, nt, n, nb;
+  // inverse
+  double* Rinv;          // nb matrices of n x n
+  // gradient
+  const double* X;
+  int d, K;
+  const double* params;
+  int ldp, draw0;
+  double sigma2;
+  const double* alpha;   // nb x npad
+  double* gpart;         // nb x ntiles x P
+};
+
+// One 128 x 128 tile (ta >= tb) of R^-1 = Z Z' (k from block ta on, where both row blocks are
+// non-zero), kept in registers and either written out (GRAD = false) or contracted on the spot
+// with the kernel derivatives (GRAD = true):
+//   M = (alpha alpha' - R^-1 / c) / 2,  c = sigma2 sum w^2,  alpha = R^-1 (y - beta 1) / c
+//   d loglik / d w_q      =  2 sigma2 w_q     sum_ab M_ab R_q,ab
+//   d loglik / d theta_qk = -  sigma2 w_q^2   sum_ab M_ab (x_ak - x_bk)^2 R_q,ab
+// R_q is regenerated from X (never stored).  One workgroup per CU (512 VGPRs): the tile of M R_q
+// lives in registers next to the accumulators.
+template <bool GRAD>
+__global__ __launch_bounds__(256, 1) void rinv_tile_kernel(RinvArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int ntiles = g.nt * (g.nt + 1) / 2;
+  const int L = blockIdx.x;
+  const int per_grp = 8 * ntiles;
+  const int grp = L / per_grp, rr = L % per_grp;
+  const int b = grp * 8 + (rr & 7);
+  const int t = rr >> 3;
+  if (b >= g.nb) return;
+  int ta = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((ta + 1) * (ta + 2) / 2 <= t) ++ta;
+  while (ta * (ta + 1) / 2 > t) --ta;
+  const int tb = t - ta * (ta + 1) / 2;
+
+  const double* Zb = g.A + (size_t)b * g.a_stride + g.npad + kTile;
+  const double* P = Zb + (size_t)ta * kTile + (size_t)ta * kTile * g.ld;
+  const double* Q = Zb + (size_t)tb * kTile + (size_t)ta * kTile * g.ld;
+  d4 acc[4][4];
+  gemm_accumulate<1, false>(smem, P, g.ld, Q, g.ld, g.npad - ta * kTile, acc);
+  // acc[x][y][r] = Rinv[row = ta*128 + row0 + 16y + l15][col = tb*128 + col0 + 16x + l4 + 4r]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = TileGeom<1, false>::row0(wave), col0 = TileGeom<1, false>::col0(wave);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int n = g.n;
+  if constexpr (!GRAD) {
+    double* out = g.Rinv + (size_t)b * n * n;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ga = ta * kTile + row0 + y * 16 + l15, gb = tb * kTile + col0 + x * 16 + l4 + 4 * r;
+          if (ga < n && gb < n) {
+            out[ga + (size_t)gb * n] = acc[x][y][r];
+            out[gb + (size_t)ga * n] = acc[x][y][r];
+          }
+        }
+    return;
+  } else {
+    const int d = g.d, K = g.K, Pn = K + K * d;
+    const int gdraw = g.draw0 + b;
+    // the staging LDS is free (the K loop ended on a barrier)
+    double* xa = smem;                 // [d][128]
+    double* xb = xa + d * kTile;       // [d][128]
+    double* ua = xb + d * kTile;       // [K][128]
+    double* ub = ua + K * kTile;       // [K][128]
+    double* al_a = ub + K * kTile;     // [128]
+    double* al_b = al_a + kTile;       // [128]
+    double* th = al_b + kTile;         // [K][d]
+    double* w2 = th + K * d;           // [K]
+    double* part = w2 + K;             // [4][Pn]
+    for (int e = tid; e < K * d; e += 256) th[e] = g.params[gdraw + (size_t)(K + e) * g.ldp];
+    if (tid < K) { const double w = g.params[gdraw + (size_t)tid * g.ldp]; w2[tid] = w * w; }
+    for (int e = tid; e < d * kTile; e += 256) {
+      const int k = e / kTile, r = e % kTile;
+      const int ga = ta * kTile + r, gb = tb * kTile + r;
+      xa[e] = ga < n ? g.X[ga + (size_t)k * n] : 0.0;
+      xb[e] = gb < n ? g.X[gb + (size_t)k * n] : 0.0;
+    }
+    if (tid < kTile) {
+      al_a[tid] = g.alpha[(size_t)b * g.npad + ta * kTile + tid];
+      al_b[tid] = g.alpha[(size_t)b * g.npad + tb * kTile + tid];
+    }
+    __syncthreads();
+    for (int e = tid; e < K * kTile; e += 256) {
+      const int q = e / kTile, r = e % kTile;
+      double sa = 0.0, sb = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double tq = th[q * d + k], va = xa[k * kTile + r], vb = xb[k * kTile + r];
+        sa += va * va * tq;
+        sb += vb * vb * tq;
+      }
+      ua[e] = sa;
+      ub[e] = sb;
+    }
+    __syncthreads();
+    double sw = 0.0;
+    for (int q = 0; q < K; ++q) sw += w2[q];
+    const double cs = g.sigma2 * sw;
+    const double sym = ta == tb ? 1.0 : 2.0;   // lower tiles only: off-diagonal tiles count twice
+    // M in place of the accumulators (zero outside the n x n matrix)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = row0 + y * 16 + l15, lc = col0 + x * 16 + l4 + 4 * r;
+          const int ga = ta * kTile + lr, gb = tb * kTile + lc;
+          const double m = 0.5 * (al_a[lr] * al_b[lc] / (cs * cs) - acc[x][y][r] / cs);
+          acc[x][y][r] = (ga < n && gb < n) ? sym * m : 0.0;
+        }
+    for (int q = 0; q < K; ++q) {
+      d4 T[4][4];   // M .* R_q
+      double gsum = 0.0;
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lr = row0 + y * 16 + l15, lc = col0 + x * 16 + l4 + 4 * r;
+            double sdot = 0.0;
+            for (int k = 0; k < d; ++k) sdot = fma(xa[k * kTile + lr] * th[q * d + k], xb[k * kTile + lc], sdot);
+            const double dist = (ua[q * kTile + lr] + ub[q * kTile + lc]) + (-2.0 * sdot);
+            const double v = acc[x][y][r] * exp(-dist);
+            T[x][y][r] = v;
+            gsum += v;
+          }
+      for (int off = 32; off > 0; off >>= 1) gsum += __shfl_down(gsum, off, 64);
+      if (lane == 0) part[wave * Pn + q] = gsum;
+      for (int k = 0; k < d; ++k) {
+        double hsum = 0.0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int lr = row0 + y * 16 + l15, lc = col0 + x * 16 + l4 + 4 * r;
+              const double df = xa[k * kTile + lr] - xb[k * kTile + lc];
+              hsum = fma(T[x][y][r], df * df, hsum);
+            }
+        for (int off = 32; off > 0; off >>= 1) hsum += __shfl_down(hsum, off, 64);
+        if (lane == 0) part[wave * Pn + K + q * d + k] = hsum;
+      }
+    }
+    __syncthreads();
+    if (tid < Pn)
+      g.gpart[((size_t)b * ntiles + t) * Pn + tid] =
+          (part[tid] + part[Pn + tid]) + (part[2 * Pn + tid] + part[3 * Pn + tid]);
+  }
+}
+
+struct GradReduceArgs {
+  const double* gpart;
+  int ntiles, P, K, d, nb, b0, Btot;
+  const double* params;
+  int ldp;
+  double sigma2;
+  const int* status;
+  double* grad;
+};
+
+__global__ void blocked_grad_reduce_kernel(GradReduceArgs g) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= g.nb * g.P) return;
+  const int b = idx / g.P, q = idx % g.P, gb = g.b0 + b;
+  double s = 0.0;
+  for (int t = 0; t < g.ntiles; ++t) s += g.gpart[((size_t)b * g.ntiles + t) * g.P + q];
+  const int c = q < g.K ? q : (q - g.K) / g.d;
+  const double wc = g.params[gb + (size_t)c * g.ldp];
+  double v = q < g.K ? 2.0 * g.sigma2 * wc * s : -g.sigma2 * wc * wc * s;
+  if (g.status && g.status[gb] != 0) v = __longlong_as_double(0x7ff8000000000000LL);
+  g.grad[gb + (size_t)q * g.Btot] = v;
+}
+
 }  // namespace
 
 size_t blocked_ws_bytes(int npad, int nb, int ne) {
@@ -511,12 +757,13 @@ BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
 static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n, int d, const double* y,
                           DrawView dv, int b0, int nb, int npad, double sigma2, int mean_mode,
                           double tau2, BlockedWs w, double* loglik, double* beta, int* status,
-                          const BlockedPredict* pr) {
+                          const BlockedJob* job) {
+  const BlockedJob* pr = job && job->kind == kJobPredict ? job : nullptr;
   const int nt = npad / kTile;
   {
     ScopedTimer t(h, CCGP_T_COV, s);
     launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld);
-    RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld};
+    RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
     hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
     if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site
       launch_cov_cross_batched(s, pr->Xtest, pr->m, X, n, d, dv, b0, nb, w.A + npad + kTile, w.a_stride,
@@ -525,6 +772,7 @@ static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n,
   GemmArgs g{};
   g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
   g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb; g.ld = w.ld; g.ne = w.ne;
+  g.extra_lower = job && job->kind >= kJobInverse ? 1 : 0;
   DiagArgs dg{};
   dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
   dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
@@ -566,17 +814,45 @@ static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n,
       hipLaunchKernelGGL(predict_finish_kernel, dim3((pr->m + 255) / 256, nb), dim3(256), 0, s, pa);
     }
   }
+  if (job && job->kind >= kJobInverse) {
+    ScopedTimer t(h, CCGP_T_SOLVE, s);
+    const int ntiles = nt * (nt + 1) / 2;
+    RinvArgs ra{};
+    ra.A = w.A; ra.a_stride = w.a_stride; ra.npad = npad; ra.ld = w.ld; ra.nt = nt; ra.n = n; ra.nb = nb;
+    const dim3 grid(round_up(nb, 8) * ntiles), block(256);
+    if (job->kind == kJobInverse) {
+      ra.Rinv = job->Rinv;
+      hipLaunchKernelGGL(rinv_tile_kernel<false>, grid, block, gemm_lds_bytes<1>(), s, ra);
+    } else {
+      const int P = dv.K + dv.K * d;
+      AlphaArgs aa{w.A, w.a_stride, npad, w.ld, n, w.fin + nb, job->alpha};
+      hipLaunchKernelGGL(alpha_kernel, dim3((npad + 255) / 256, nb), dim3(256), 0, s, aa);
+      ra.X = X; ra.d = d; ra.K = dv.K; ra.params = dv.params; ra.ldp = dv.ldp; ra.draw0 = b0;
+      ra.sigma2 = sigma2; ra.alpha = job->alpha; ra.gpart = job->gpart;
+      hipLaunchKernelGGL(rinv_tile_kernel<true>, grid, block, gemm_lds_bytes<1>(), s, ra);
+      GradReduceArgs ga{job->gpart, ntiles, P, dv.K, d, nb, b0, job->Btot, dv.params, dv.ldp, sigma2,
+                        status, job->grad};
+      hipLaunchKernelGGL(blocked_grad_reduce_kernel, dim3((nb * P + 255) / 256), dim3(256), 0, s, ga);
+    }
+  }
+}
+
+// LDS scratch of the gradient contraction must fit the S = 1 staging area
+bool blocked_grad_supported(int d, int K) {
+  return sizeof(double) * ((size_t)(2 * d + 2 * K + 2) * kTile + (size_t)K * d + K + 4 * (K + K * d)) <=
+         gemm_lds_bytes<1>();
 }
 
 void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
-                    BlockedWs w, double* loglik, double* beta, int* status, const BlockedPredict* pr) {
+                    BlockedWs w, double* loglik, double* beta, int* status, const BlockedJob* job) {
   const int nt = npad / kTile;
   static bool attr_set = false;
   if (!attr_set) {
     const void* ks[] = {(const void*)chol_update_kernel, (const void*)chol_update_s2_kernel,
                         (const void*)chol_update_s4_kernel, (const void*)chol_trsm_kernel,
-                        (const void*)chol_trsm_s2_kernel, (const void*)chol_trsm_s4_kernel};
+                        (const void*)chol_trsm_s2_kernel, (const void*)chol_trsm_s4_kernel,
+                        (const void*)rinv_tile_kernel<false>, (const void*)rinv_tile_kernel<true>};
     for (const void* k : ks)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
     attr_set = true;
@@ -584,11 +860,12 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   // split the nb matrices into independent groups (multiples of 8 matrices: the XCD-aware
   // block decode keeps 8 matrices per XCD group) and fork them onto the group streams
   int ng = h->n_groups;
+  if (job && job->kind >= kJobInverse) ng = 1;   // their scratch is addressed per chunk, not per group
   if (ng > nb / 8) ng = nb / 8;
   if (ng < 1) ng = 1;
   if (ng == 1) {
     blocked_group(h, h->stream, X, n, d, y, dv, b0, nb, npad, sigma2, mean_mode, tau2, w, loglik, beta,
-                  status, pr);
+                  status, job);
     return;
   }
   (void)hipEventRecord(h->fork, h->stream);
@@ -603,7 +880,7 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
     wg.z = w.z + (size_t)m0 * nt;
     wg.fin = w.fin + (size_t)2 * m0;   // (s11, beta) pairs are addressed as fin[0..cnt) and fin[cnt..2cnt)
     blocked_group(h, s, X, n, d, y, dv, b0 + m0, cnt, npad, sigma2, mean_mode, tau2, wg, loglik, beta,
-                  status, pr);
+                  status, job);
     (void)hipEventRecord(h->gjoin[gidx], s);
     (void)hipStreamWaitEvent(h->stream, h->gjoin[gidx], 0);
   }

@@ -540,10 +540,58 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || B < 1 || !X || !y || !params || !out_grad)
     return fail(h, CCGP_EINVAL, "ccgp_loglik_grad_batch: bad argument");
-  if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)
-    return fail(h, CCGP_EUNSUPPORTED, "ccgp_loglik_grad_batch: n > 128 (or a design too wide for LDS) not implemented yet");
   CCGP_HIP(hipSetDevice(h->device));
   const int P = K + K * d;
+  if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
+    // blocked path: identity rows ride along as extra tile rows, then R^-1 tiles are formed in
+    // registers and contracted with the kernel derivatives (blocked.hip, rinv_tile_kernel)
+    if (!blocked_grad_supported(d, K))
+      return fail(h, CCGP_EUNSUPPORTED, "ccgp_loglik_grad_batch: d + K too large for the contraction kernel's LDS");
+    const int npad = round_up(n, kTile), nt = npad / kTile, ne = nt, ntiles = nt * (nt + 1) / 2;
+    const size_t per_extra = sizeof(double) * ((size_t)ntiles * P + npad);
+    size_t per = blocked_ws_bytes(npad, 1, ne) + per_extra;
+    int nbc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, h->ws_limit / per));
+    size_t need_st = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                     2 * Carver::al(sizeof(double) * (size_t)B * P) + 2 * Carver::al(sizeof(double) * B) +
+                     Carver::al(sizeof(int) * (size_t)B);
+    int rc = ensure_stage(h, need_st);
+    if (rc) return rc;
+    rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, ne) + (size_t)nbc * per_extra + 512);
+    if (rc) return rc;
+    Carver c(h->stage);
+    double* dX = c.take<double>((size_t)n * d);
+    double* dy = c.take<double>(n);
+    double* dp = c.take<double>((size_t)B * P);
+    double* dg = c.take<double>((size_t)B * P);
+    double* dll = c.take<double>(B);
+    double* dbeta = c.take<double>(B);
+    int* dst = c.take<int>(B);
+    CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemsetAsync(dst, 0, sizeof(int) * (size_t)B, h->stream));
+    DrawView dv{dp, B, K, d};
+    Carver tail(static_cast<char*>(h->ws) + Carver::al(blocked_ws_bytes(npad, nbc, ne)));
+    BlockedJob job{};
+    job.kind = kJobGrad; job.grad = dg; job.Btot = B;
+    job.gpart = tail.take<double>((size_t)nbc * ntiles * P);
+    job.alpha = tail.take<double>((size_t)nbc * npad);
+    for (int b0 = 0; b0 < B; b0 += nbc) {
+      const int nb = std::min(nbc, B - b0);
+      BlockedWs w = blocked_carve(h->ws, npad, nb, ne);
+      blocked_loglik(h, dX, n, d, dy, dv, b0, nb, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, dll, dbeta,
+                     dst, &job);
+    }
+    CCGP_HIP(hipGetLastError());
+    std::vector<int> st(B);
+    if (out_loglik) CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+    if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipMemcpyAsync(out_grad, dg, sizeof(double) * (size_t)B * P, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+    if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
+    return count_bad(st.data(), B);
+  }
   const int nch = small_grad_chunks(n, d);
   size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
                 2 * Carver::al(sizeof(double) * (size_t)B * P) + 2 * Carver::al(sizeof(double) * B) +
@@ -621,9 +669,37 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   int rc = ccgp_loglik_batch(h, X, n, d, y, K, row.data(), 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0,
                              &ll, &beta, &st);
   if (rc < 0) return rc;
-  if (out_Rinv) {
-    if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)
-      return fail(h, CCGP_EUNSUPPORTED, "ccgp_logpost: R.Inv output for n > 128 (or a design too wide for LDS) not implemented yet");
+  if (out_Rinv && (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)) {
+    // blocked path: one more sweep with the identity as extra rows, then R^-1 = Z Z' tile by tile
+    const int npad = round_up(n, kTile), nt = npad / kTile;
+    size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                  Carver::al(sizeof(double) * P) + Carver::al(sizeof(double) * (size_t)n * n) +
+                  3 * Carver::al(sizeof(double) * 2) + 256;
+    int rc2 = ensure_stage(h, need);
+    if (rc2) return rc2;
+    rc2 = ensure_ws(h, blocked_ws_bytes(npad, 1, nt));
+    if (rc2) return rc2;
+    Carver c(h->stage);
+    double* dX = c.take<double>((size_t)n * d);
+    double* dy = c.take<double>(n);
+    double* dp = c.take<double>(P);
+    double* dR = c.take<double>((size_t)n * n);
+    double* dll = c.take<double>(1);
+    double* dbt = c.take<double>(1);
+    int* dst = c.take<int>(1);
+    CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemcpyAsync(dp, row.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemsetAsync(dst, 0, sizeof(int), h->stream));
+    DrawView dv{dp, 1, K, d};
+    BlockedJob job{};
+    job.kind = kJobInverse; job.Rinv = dR;
+    BlockedWs w = blocked_carve(h->ws, npad, 1, nt);
+    blocked_loglik(h, dX, n, d, dy, dv, 0, 1, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, dll, dbt, dst, &job);
+    CCGP_HIP(hipGetLastError());
+    CCGP_HIP(hipMemcpyAsync(out_Rinv, dR, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+  } else if (out_Rinv) {
     size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * P) +
                   Carver::al(sizeof(double) * (size_t)n * n) + 256;
     int rc2 = ensure_stage(h, need);
@@ -772,7 +848,8 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
     double* bt = d_beta ? d_beta : tail.take<double>(S);
     int* st = d_status ? d_status : tail.take<int>(S);
     CCGP_HIP(hipMemsetAsync(st, 0, sizeof(int) * (size_t)S, h->stream));
-    BlockedPredict pr{dXtest, m, S, d_mean, d_var};
+    BlockedJob pr{};
+    pr.kind = kJobPredict; pr.Xtest = dXtest; pr.m = m; pr.S = S; pr.mean = d_mean; pr.var = d_var;
     for (int b0 = 0; b0 < S; b0 += nbc) {
       const int nb = std::min(nbc, S - b0);
       BlockedWs w = blocked_carve(h->ws, npad, nb, ne);

@@ -111,13 +111,24 @@ struct BlockedWs {
   int ld;           // npad + 128 * (1 + ne)
   int ne;           // extra full tile rows (ceil(m / 128) for prediction, else 0)
 };
-// optional prediction request riding on a blocked sweep (a10 + a11 for n > 128)
-struct BlockedPredict {
+// optional extra work riding on a blocked sweep (n > 128)
+enum { kJobPredict = 1, kJobInverse = 2, kJobGrad = 3 };
+struct BlockedJob {
+  int kind;
+  // kJobPredict (a10 + a11): m cross-correlation rows ride along as extra tile rows
   const double* Xtest;  // m x d, device
   int m, S;
   double* mean;         // S x m column-major, device
   double* var;
+  // kJobInverse (solve(R), HX:454): identity rows ride along; Rinv = n x n per matrix of the chunk
+  double* Rinv;
+  // kJobGrad: d loglik / d params; grad is Btot x P column-major
+  double* grad;
+  int Btot;
+  double* gpart;        // scratch: nb x ntiles x P partial sums
+  double* alpha;        // scratch: nb x npad,  R^-1 (y - beta 1)
 };
+bool blocked_grad_supported(int d, int K);
 size_t blocked_ws_bytes(int npad, int nb, int ne);
 BlockedWs blocked_carve(void* ws, int npad, int nb, int ne);
 // factorise nb matrices in place and finish the likelihood; loglik/beta/status are
@@ -125,7 +136,7 @@ BlockedWs blocked_carve(void* ws, int npad, int nb, int ne);
 void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
                     BlockedWs w, double* loglik, double* beta, int* status,
-                    const BlockedPredict* pr = nullptr);
+                    const BlockedJob* job = nullptr);
 
 // ---- special.cpp ---------------------------------------------------------------------
 void halton_base2(int N, double* out);

@@ -115,7 +115,8 @@ int ccgp_loglik_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const 
 
 /* build-defined extension (the reference has no analytic gradient; LearnBayes::laplace
  * differences numerically, HX:493): d loglik(mode 0, beta profiled) / d params[b, j],
- * out_grad is B x P column-major. */
+ * out_grad is B x P column-major.  Any n: n <= 128 in LDS; larger n carries the identity as
+ * extra tile rows of the blocked sweep and contracts R^-1 tiles with the kernel derivatives. */
 int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
                            const double* params, int B, double sigma2, double* out_loglik,
                            double* out_beta, double* out_grad, int* status);
@@ -123,8 +124,8 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
 /* ---- a8 (+a13): logpost(D.train, theta, y, sigma2[, pars]) -> list(val, beta, R.Inv) --
  * theta_t = (psi1, psi2, phi[, zeta]) on the transformed scale; prior_pars =
  * (a1,b1,a2,b2) for CCGP_PRIOR_INVGAMMA, ignored otherwise.  out_loglik (the bare
- * dmnorm term; ADV:470 returns its exp) and out_Rinv (n x n, solve(R) of HX:454) may be
- * NULL. *status as in the batch call. */
+ * dmnorm term; ADV:470 returns its exp) and out_Rinv (n x n, solve(R) of HX:454; any n) may
+ * be NULL. *status as in the batch call. */
 int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2,
                  int prior_id, const double* theta_t, const double* prior_pars, double* out_val,
                  double* out_beta, double* out_loglik, double* out_Rinv, int* status);

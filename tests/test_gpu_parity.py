@@ -335,6 +335,60 @@ def test_blocked_path_prediction(handle, n, m):
     np.testing.assert_allclose(var, wv, rtol=1e-7, atol=1e-9 * 1.7)
 
 
+def test_blocked_path_gradient_and_inverse(handle):
+    """n > 128: identity rows ride along as extra tile rows, R^-1 tiles are formed in registers
+    and contracted with the kernel derivatives (gradient) or written out (solve(R), HX:454)."""
+    n, d, K = 300, 3, 2
+    X, y = synthetic_design(n, d, seed=77)
+    rows = np.stack([np.concatenate([[0.7, 0.3], [3.0, 4.0, 5.0], [40.0, 50.0, 60.0]]),
+                     np.concatenate([[0.5, 0.5], [6.0, 2.0, 9.0], [80.0, 30.0, 45.0]])])
+    ll, beta, grad, st = handle.loglik_grad_batch(X, y, K, rows, 1.3)
+    assert not st.any()
+    for b in range(2):
+        w, Th = orc.unpack_params(rows[b], K, d)
+        wl, wb = orc.loglik_general(X, y, w, Th, 1.3)
+        assert ll[b] == pytest.approx(wl, rel=1e-9) and beta[b] == pytest.approx(wb, rel=1e-8, abs=1e-11)
+        fd = orc.loglik_grad_fd(X, y, rows[b], K, d, 1.3)
+        np.testing.assert_allclose(grad[b], fd, rtol=2e-5, atol=2e-5 * np.abs(fd).max())
+    # explicit inverse through logpost (isotropic GV script), n = 300 and a ragged n = 257
+    from ccgp_amd.rsurface import CombinedGP
+    gp = CombinedGP("GV", handle=handle)
+    for nn in (300, 257):
+        t = [math.log(4.0), math.log(50.0), 0.8]
+        r = gp.logpost(X[:nn], t, y[:nn], 1.3)
+        want = orc.logpost(X[:nn], t, y[:nn], 1.3, "GV")
+        assert r["val"] == pytest.approx(want["val"], rel=1e-9)
+        np.testing.assert_allclose(r["R_Inv"], want["R_inv"], rtol=1e-7, atol=1e-8 * np.abs(want["R_inv"]).max())
+
+
+def test_gradient_at_n4096_matches_central_differences_of_the_device_likelihood(handle):
+    """Full BASELINE config 4 size: the analytic gradient (identity rows + R^-1 contraction)
+    against central differences of the device log-likelihood itself, every coordinate."""
+    import time
+    n, d, K = 4096, 5, 3
+    X, y = synthetic_design(n, d, seed=20140101)
+    rng = np.random.default_rng(3)
+    w = 0.15 + 0.55 * rng.dirichlet(np.ones(K))
+    th = np.exp(rng.uniform(np.log(0.5), np.log(50.0), size=(K, d)))
+    th[-1] = np.maximum(th[-1], 20.0)
+    row = np.concatenate([w, th.ravel()])
+    t0 = time.perf_counter()
+    ll, beta, grad, st = handle.loglik_grad_batch(X, y, K, row[None], 1.0)
+    t_grad = time.perf_counter() - t0
+    assert st[0] == 0 and np.all(np.isfinite(grad))
+    P = row.size
+    pert = np.repeat(row[None], 2 * P, axis=0)
+    hstep = 1e-5 * np.maximum(1.0, np.abs(row))
+    for j in range(P):
+        pert[2 * j, j] += hstep[j]
+        pert[2 * j + 1, j] -= hstep[j]
+    llp, _, stp = handle.loglik_batch(X, y, K, pert, 1.0)
+    assert not stp.any()
+    fd = (llp[0::2] - llp[1::2]) / (2 * hstep)
+    np.testing.assert_allclose(grad[0], fd, rtol=5e-4, atol=5e-4 * np.abs(fd).max())
+    print("n=4096 gradient (1 draw, host API incl. allocation): %.1f ms" % (1e3 * t_grad))
+
+
 def test_small_and_blocked_agree_across_the_cutover(handle):
     """n = 128 runs the fused kernel, n = 129 the blocked one: appending one far-away,
     nearly independent point must change the likelihood by exactly its own marginal term."""

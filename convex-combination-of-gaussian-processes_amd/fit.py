@@ -1,0 +1,299 @@
+"""Host-side counterpart of the reference's inference layer: `laplace`, `Metro`,
+`factors.frame`, `prediction`, `compare.GP`, `Combined.GP.fit` on top of the device evaluator.
+
+This layer is sequential and RNG-driven in the reference (HX:483-540, HX:686-725); it is not
+accelerated, only re-hosted so that the hot path has a complete caller.  Every likelihood /
+prediction it needs goes through libccgp (`rsurface.CombinedGP`).  RNG contract: numpy
+`Generator` (PCG64) seeded by the caller -- R's Mersenne-Twister stream cannot be reproduced
+without R, so agreement with the reference is statistical, never bitwise.
+
+Reference behaviours kept on purpose (they shape the output):
+  * only ACCEPTED proposals are stored and counted (`samp[k,] <- theta.candidate`, HX:515-522);
+  * the proposal covariance is sqrt(2) * V_laplace (HX:511);
+  * the Geweke stop rule looks at `samp[(k-samp.size):(k-1)]`, which indexes the N x p matrix
+    as a vector, i.e. the FIRST parameter's chain only (HX:530);
+  * the predictive interval is the empirical quantile of one rnorm draw per posterior draw
+    (HX:696-699), type-7 quantiles.
+Third-party pieces restated from their definitions: LearnBayes::laplace (optim Nelder-Mead +
+finite-difference Hessian), coda::geweke.diag (first 10 % vs last 50 %, spectral density at
+zero from an AIC-selected AR fit), mlegp's sigma2 (ordinary-kriging MLE; here a deterministic
+L-BFGS on the concentrated likelihood instead of mlegp's randomised simplex restarts).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import api
+
+
+# ----------------------------------------------------------------------------- priors / Jacobian (host)
+def log_jacobian(theta_t):
+    """-phi - 2 log(1 + e^-phi) + psi1 + psi2 [+ zeta]  (HX:461, ANI:459); vectorised over rows."""
+    t = np.atleast_2d(np.asarray(theta_t, dtype=np.float64))
+    val = -t[:, 2] - 2.0 * np.log1p(np.exp(-t[:, 2])) + t[:, 0] + t[:, 1]
+    if t.shape[1] == 4:
+        val = val + t[:, 3]
+    return val
+
+
+def log_prior(theta_t, script, prior_pars=None):
+    """HX:462 / ADV:467, GV:450, ISO:453 = BSQ:450, ANI:462; vectorised over rows."""
+    t = np.atleast_2d(np.asarray(theta_t, dtype=np.float64))
+    psi1, psi2 = t[:, 0], t[:, 1]
+    th1, th2 = np.exp(psi1), np.exp(psi2)
+    if script in ("HX", "ADV"):
+        a1, b1, a2, b2 = prior_pars
+        return -(a1 + 1.0) * psi1 - b1 / th1 - (a2 + 1.0) * psi2 - b2 / th2
+    if script == "GV":
+        return -4.0 * psi1 - 1.0 / th1 - 6.0 * psi2 - 75.0 / th2
+    if script in ("ISO", "BSQ"):
+        return -4.0 * psi1 - 2.0 / th1 - 6.0 * psi2 - 16.0 / th2
+    if script == "ANI":
+        zeta = t[:, 3]
+        return -psi1 - psi1 ** 2 / 2.0 - psi2 - psi2 ** 2 / 2.0 - 4.0 * zeta - 4.0 / np.exp(zeta)
+    raise ValueError(script)
+
+
+def transformed_to_draws(theta_t):
+    """(psi1, psi2, phi[, zeta]) rows -> (p, theta1, theta2[, lambda]) rows (HX:631-636)."""
+    t = np.atleast_2d(np.asarray(theta_t, dtype=np.float64))
+    cols = [1.0 / (1.0 + np.exp(-t[:, 2])), np.exp(t[:, 0]), np.exp(t[:, 1])]
+    if t.shape[1] == 4:
+        cols.append(np.exp(t[:, 3]))
+    return np.stack(cols, axis=1)
+
+
+def logpost_batch(gp, D_train, theta_t, y, sigma2, prior_pars=None):
+    """`logpost(...)$val` for MANY transformed draws in one device call -> (val, beta).
+    Rows whose covariance cannot be factorised give NaN (the reference's NA, HX:454-455)."""
+    t = np.atleast_2d(np.asarray(theta_t, dtype=np.float64))
+    draws = transformed_to_draws(t)
+    params = gp.draws_to_params(D_train, draws)
+    ll, beta, _ = gp.h.loglik_batch(D_train, y, 2, params, sigma2, api.MEAN_PROFILE_BETA, 0.0)
+    return ll + log_jacobian(t) + log_prior(t, gp.script, prior_pars), beta
+
+
+# ----------------------------------------------------------------------------- LearnBayes::laplace
+def laplace(fn_batch, start, hess_step=1e-3, maxiter=2000):
+    """Posterior mode by Nelder-Mead and covariance = -H^-1 from central differences
+    (LearnBayes::laplace -> optim(..., hessian = TRUE); HX:493).  `fn_batch(rows) -> values`."""
+    from scipy.optimize import minimize
+
+    start = np.asarray(start, dtype=np.float64)
+
+    def neg(x):
+        v = float(fn_batch(x[None])[0])
+        return 1e300 if not math.isfinite(v) else -v
+
+    res = minimize(neg, start, method="Nelder-Mead",
+                   options=dict(xatol=1e-6, fatol=1e-9, maxiter=maxiter, maxfev=maxiter))
+    mode = res.x
+    p = mode.size
+    pts, idx = [], []
+    for i in range(p):
+        for j in range(i, p):
+            for si, sj in ((1, 1), (1, -1), (-1, 1), (-1, -1)):
+                x = mode.copy()
+                x[i] += si * hess_step
+                x[j] += sj * hess_step
+                pts.append(x)
+            idx.append((i, j))
+    vals = np.asarray(fn_batch(np.asarray(pts)), dtype=np.float64).reshape(-1, 4)
+    H = np.zeros((p, p))
+    for (i, j), v in zip(idx, vals):
+        H[i, j] = H[j, i] = (v[0] - v[1] - v[2] + v[3]) / (4.0 * hess_step ** 2)
+    try:
+        var = -np.linalg.inv(H)
+        np.linalg.cholesky(var)
+    except np.linalg.LinAlgError:
+        var = np.diag(1.0 / np.maximum(-np.diag(H), 1e-6))   # not negative definite: fall back to its diagonal
+    return dict(mode=mode, var=var, converged=bool(res.success), value=-float(res.fun))
+
+
+# ----------------------------------------------------------------------------- coda::geweke.diag
+def _spectrum0_ar(x):
+    """Spectral density at frequency zero from an AR(p) fit, p chosen by AIC (coda::spectrum0.ar)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.size
+    xc = x - x.mean()
+    v0 = float(xc @ xc) / n
+    if v0 == 0.0:
+        return 0.0
+    pmax = min(n - 1, int(10 * math.log10(n)))
+    r = np.array([float(xc[: n - k] @ xc[k:]) / n for k in range(pmax + 1)])
+    best = (n * math.log(v0), 0, v0, np.zeros(0))
+    phi = np.zeros(0)
+    var = v0
+    for p in range(1, pmax + 1):          # Levinson-Durbin
+        kappa = (r[p] - float(phi @ r[p - 1:0:-1])) / var if p > 1 else r[1] / r[0]
+        phi = np.concatenate([phi - kappa * phi[::-1], [kappa]])
+        var = var * (1.0 - kappa ** 2)
+        if var <= 0:
+            break
+        aic = n * math.log(var) + 2 * p
+        if aic < best[0]:
+            best = (aic, p, var, phi.copy())
+    _, p, var, phi = best
+    var_pred = var * n / max(n - (p + 1), 1)
+    return var_pred / (1.0 - phi.sum()) ** 2
+
+
+def geweke_z(x, frac1=0.1, frac2=0.5):
+    x = np.asarray(x, dtype=np.float64)
+    n = x.size
+    a = x[: max(int(math.floor(frac1 * n)), 2)]
+    b = x[n - max(int(math.floor(frac2 * n)), 2):]
+    va, vb = _spectrum0_ar(a) / a.size, _spectrum0_ar(b) / b.size
+    if not (va + vb > 0):
+        raise FloatingPointError("degenerate chain")
+    return (a.mean() - b.mean()) / math.sqrt(va + vb)
+
+
+# ----------------------------------------------------------------------------- Metro / factors.frame
+def Metro(gp, start, N, samp_size, batch_size, alpha, D_train, sigma2, y, theta1_pars=None,
+          theta2_pars=None, rng=None, max_proposals=None):
+    """HX:483-540 (and its per-script copies).  Returns dict(sample[samp_size, p], beta[samp_size],
+    accepted, proposals, laplace)."""
+    from scipy.stats import norm
+
+    rng = np.random.default_rng(rng)
+    pars = None
+    if gp.script in ("HX", "ADV"):
+        pars = (*np.ravel(theta1_pars)[:2], *np.ravel(theta2_pars)[:2])
+
+    def val_batch(rows):
+        return logpost_batch(gp, D_train, rows, y, sigma2, pars)[0]
+
+    est = laplace(val_batch, start)
+    mu, V = est["mode"], est["var"]
+    cov = math.sqrt(2.0) * V
+    p = mu.size
+    samp = np.zeros((N, p))
+    betas = np.zeros(N)
+    theta_old = mu.copy()
+    l_old, _ = logpost_batch(gp, D_train, theta_old[None], y, sigma2, pars)
+    l_old = float(l_old[0])
+    k, pv, proposals = 0, 0.0, 0
+    max_proposals = max_proposals or 200 * N
+    while k < N and pv < alpha and proposals < max_proposals:
+        u = rng.random()
+        cand = rng.multivariate_normal(theta_old, cov)
+        proposals += 1
+        l_cand, b_cand = logpost_batch(gp, D_train, cand[None], y, sigma2, pars)
+        l_cand = float(l_cand[0])
+        if math.isfinite(l_cand) and (l_cand - l_old) > math.log(u):
+            samp[k] = cand
+            betas[k] = b_cand[0]
+            theta_old, l_old = cand, l_cand
+            k += 1
+            if k >= samp_size and k % batch_size == 0:
+                try:   # first parameter's chain over the last samp_size + 1 accepted draws (HX:530)
+                    z = geweke_z(samp[max(k - samp_size - 1, 0):k, 0])
+                    pv = float(2.0 * (1.0 - norm.cdf(abs(z))))
+                except Exception:
+                    pv = 0.0
+    if k < samp_size:
+        raise RuntimeError("Metro: only %d accepted draws after %d proposals" % (k, proposals))
+    return dict(sample=samp[k - samp_size:k].copy(), beta=betas[k - samp_size:k].copy(), accepted=k,
+                proposals=proposals, laplace=est, geweke_p=pv)
+
+
+def factors_frame(gp, start, N, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train,
+                  net_samp_size, theta1_pars=None, theta2_pars=None, rng=None):
+    """HX:625-644 without materialising R.Inv per draw: returns the retained posterior draws
+    (p, theta1, theta2[, lambda]) and their beta; the device recomputes the factor when predicting
+    (rsurface.CombinedGP.factors_frame_from_draws builds the reference's wide frame on request)."""
+    s = Metro(gp, start, N, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train, theta1_pars,
+              theta2_pars, rng)
+    keep = slice(samp_size - net_samp_size, samp_size)
+    return dict(draws=transformed_to_draws(s["sample"][keep]), beta=s["beta"][keep], chain=s)
+
+
+# ----------------------------------------------------------------------------- prediction / compare.GP
+def compare_GP(gp, D_test, alpha, y_test, draws, D_train, sigma2, y_train, rng=None):
+    """HX:713-725 + prediction HX:686-703 (GV:620-646 adds Quant.Combined): one row per test point
+    (y.hat.Combined, Quant.Combined, LL.Combined, UL.Combined, y.true)."""
+    rng = np.random.default_rng(rng)
+    t = gp.prediction_table(D_test, draws, D_train, sigma2, y_train)
+    mean, var = t["mean"], t["var"]                      # [S, m]
+    y_hat = mean.mean(axis=0)
+    post = rng.normal(mean, np.sqrt(np.maximum(var, 0.0)))
+    lo = np.quantile(post, alpha / 2.0, axis=0)
+    hi = np.quantile(post, 1.0 - alpha / 2.0, axis=0)
+    quant = (y_hat[None, :] <= post).mean(axis=0)
+    return dict(y_hat=y_hat, quant=quant, LL=lo, UL=hi, y_true=np.asarray(y_test, dtype=np.float64),
+                mean=mean, var=var)
+
+
+def ordinary_kriging_sigma2(handle, D_train, y_train, starts=3, rng=0):
+    """sigma2 of the ordinary-kriging MLE with one anisotropic Gaussian kernel -- what the scripts
+    take from mlegp (`ord$sig2`, HX:759-760).  Deterministic L-BFGS on the concentrated
+    log-likelihood using the device likelihood and its analytic gradient.
+    Returns (sigma2, theta[d], beta)."""
+    from scipy.optimize import minimize
+
+    D = np.asarray(D_train, dtype=np.float64)
+    y = np.asarray(y_train, dtype=np.float64).ravel()
+    n, d = D.shape
+    span = np.maximum(D.max(axis=0) - D.min(axis=0), 1e-12)
+
+    def parts(theta):
+        row = np.concatenate([[1.0], theta])[None]
+        a, beta, st = handle.loglik_batch(D, y, 1, row, 1.0)
+        b, _, _ = handle.loglik_batch(D, y, 1, row, math.e)
+        if st[0] != 0 or not math.isfinite(a[0]):
+            return None
+        Q = (n - 2.0 * (a[0] - b[0])) / (1.0 - 1.0 / math.e)       # (y-b)'R^-1(y-b)
+        logdet = -2.0 * a[0] - n * math.log(2 * math.pi) - Q
+        return max(Q, 1e-300), logdet, beta[0]
+
+    def f(logth):
+        theta = np.exp(logth)
+        pr = parts(theta)
+        if pr is None:
+            return 1e300, np.zeros(d)
+        Q, logdet, _ = pr
+        s2 = Q / n
+        val = -0.5 * (n * math.log(2 * math.pi) + n * math.log(s2) + logdet + n)
+        _, _, g, st = handle.loglik_grad_batch(D, y, 1, np.concatenate([[1.0], theta])[None], s2)
+        if st[0] != 0:
+            return 1e300, np.zeros(d)
+        return -val, -(g[0, 1:] * theta)                              # envelope theorem; chain rule to log theta
+
+    best = None
+    gen = np.random.default_rng(rng)
+    for s in range(starts):
+        x0 = np.log((1.0 if s == 0 else gen.uniform(0.2, 5.0, size=d)) / span ** 2)
+        res = minimize(f, x0, jac=True, method="L-BFGS-B", bounds=[(-12.0, 12.0)] * d)
+        if best is None or res.fun < best.fun:
+            best = res
+    theta = np.exp(best.x)
+    Q, _, beta = parts(theta)
+    return Q / n, theta, beta
+
+
+def Combined_GP_fit(gp, D_train, y_train, D_new, start, N_max, samp_size, alpha_geweke, batch_size,
+                    alpha=0.05, net_samp_size=None, y_new=None, sigma2=None, theta1_pars=None,
+                    theta2_pars=None, rng=None):
+    """ISO:736-783 / ANI:730-777 / D1:989-1016 minus the plots: sigma2 (ordinary kriging) ->
+    posterior draws (laplace + Metro) -> predictions with intervals at D.new."""
+    rng = np.random.default_rng(rng)
+    if sigma2 is None:
+        sigma2, _, _ = ordinary_kriging_sigma2(gp.h, D_train, y_train)
+    net = net_samp_size or samp_size
+    ff = factors_frame(gp, start, N_max, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train, net,
+                       theta1_pars, theta2_pars, rng)
+    y_new = np.full(np.asarray(D_new).shape[0], np.nan) if y_new is None else y_new
+    table = compare_GP(gp, D_new, alpha, y_new, ff["draws"], D_train, sigma2, y_train, rng)
+    table.update(sigma2=sigma2, draws=ff["draws"], beta=ff["beta"], chain=ff["chain"])
+    return table
+
+
+def comparison_summary(table):
+    """Comparison.Summary's Combined-GP figures (ANI:703-721): RMSPE and interval coverage."""
+    e = table["y_true"] - table["y_hat"]
+    cover = np.mean((table["y_true"] >= table["LL"]) & (table["y_true"] <= table["UL"]))
+    return dict(rmspe=float(np.sqrt(np.mean(e ** 2))), coverage=float(cover),
+                mean_quantile=float(np.mean(table["quant"])))

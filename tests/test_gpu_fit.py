@@ -1,0 +1,45 @@
+"""End-to-end fit/predict on the device path, checked STATISTICALLY against the only output the
+reference records (Ground Vibrations Emulator/Results/Size 50 Results 1.txt: RMSPE 2.722,
+95 % interval coverage 0.973, mean predictive quantile 0.503 -- one unseeded R run)."""
+import numpy as np
+import pytest
+
+from conftest import load_gv, load_qian
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ground_vibrations_fit_reproduces_the_recorded_run_statistically(handle):
+    from ccgp_amd import fit
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, Dt, yt = load_gv(50)
+    gp = CombinedGP("GV", handle=handle)
+    sigma2, theta, beta = fit.ordinary_kriging_sigma2(handle, D, y)
+    assert 0.1 * np.var(y) < sigma2 < 20 * np.var(y) and np.all(theta > 0)
+    # driver block GV:688-695: start c(1,1,0), N.max 5000, samp.size 1000, alpha.geweke 0.5, batch 20
+    table = fit.Combined_GP_fit(gp, D, y, Dt, [1.0, 1.0, 0.0], 5000, 1000, 0.5, 20, alpha=0.05, y_new=yt,
+                                sigma2=sigma2, rng=20140101)
+    s = fit.comparison_summary(table)
+    print("GV size-50 sample 1: RMSPE %.3f (reference run 2.722), coverage %.3f (0.973), mean quantile %.3f (0.503), "
+          "accepted %d of %d proposals" % (s["rmspe"], s["coverage"], s["mean_quantile"], table["chain"]["accepted"],
+                                           table["chain"]["proposals"]))
+    assert 2.2 < s["rmspe"] < 3.3
+    assert s["coverage"] >= 0.88
+    assert 0.40 < s["mean_quantile"] < 0.60
+    draws = table["draws"]
+    assert draws.shape == (1000, 3) and np.all((draws[:, 0] > 0) & (draws[:, 0] < 1)) and np.all(draws[:, 1:] > 0)
+
+
+def test_heat_exchanger_fit(handle):
+    from ccgp_amd import fit
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, Dt, yt = load_qian()
+    gp = CombinedGP("HX", handle=handle)
+    sigma2, _, _ = fit.ordinary_kriging_sigma2(handle, D, y)
+    # driver block HX:736-742, 774-775: start c(1,2.7,0), priors (7,3), (3,28)
+    table = fit.Combined_GP_fit(gp, D, y, Dt, [1.0, 2.7, 0.0], 5000, 1000, 0.5, 20, y_new=yt, sigma2=sigma2,
+                                theta1_pars=(7, 3), theta2_pars=(3, 28), rng=7)
+    s = fit.comparison_summary(table)
+    print("Qian: RMSPE %.3f, coverage %.2f" % (s["rmspe"], s["coverage"]))
+    assert s["rmspe"] < 0.5 * np.std(yt)          # far better than predicting the mean
+    assert s["coverage"] >= 0.7                   # 14 test points only

@@ -90,6 +90,49 @@ def cfg2_inputs():
     return X, y, P, 2, float(np.var(y, ddof=1))
 
 
+def cfg3_inputs():
+    """BASELINE config 3: maximin-100 design, anisotropic kernel (ANI:399-406), ADV grid semantics
+    (60 rows x 1728 Halton nodes, tau = 100), lambda = 4, inverse-gamma scales x16."""
+    from ccgp_amd.tables import read_table
+    from ccgp_amd import api
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    _, X = read_table(os.path.join(data, "maximin_100.txt"))
+    _, H = read_table(os.path.join(data, "adv_hyperpars_matrix.txt"))
+    H = H * np.array([1.0, 16.0, 1.0, 16.0])
+    y = (np.sin(2 * X[:, 0]) + np.cos(4 * X[:, 0])) * (np.sin(8 * X[:, 1]) + np.cos(4 * X[:, 1]))   # ANI:338
+    N, lam = 1728, 4.0
+    u = api.halton_base2(N)
+    P = np.empty((H.shape[0] * N, 6))
+    for g in range(H.shape[0]):
+        th1, th2 = api.qigamma(u, H[g, 0], H[g, 1]), api.qigamma(u, H[g, 2], H[g, 3])
+        blk = P[g * N:(g + 1) * N]
+        blk[:, 0], blk[:, 1], blk[:, 2], blk[:, 3] = u, 1.0 - u, th1, th2
+        blk[:, 4], blk[:, 5] = (1 + lam) * th1, (1 + lam) * th2
+    return X, y, P, 2, float(np.var(y, ddof=1))
+
+
+def cfg5_inputs(S=1000, seed=20140105):
+    """BASELINE config 5: every Ground-Vibrations train/test pair (9 of size 50, 8 of size 90),
+    S posterior draws synthesised around (p, theta1, theta2) = (0.7, 0.3, 15) with log-normal jitter."""
+    from ccgp_amd.tables import read_table
+    data = os.path.join(ROOT, "tests", "golden", "data", "gv")
+    rng = np.random.default_rng(seed)
+    p = 1.0 / (1.0 + np.exp(-(math.log(0.7 / 0.3) + 0.3 * rng.normal(size=S))))
+    th1 = 0.3 * np.exp(0.25 * rng.normal(size=S))
+    th2 = 15.0 * np.exp(0.25 * rng.normal(size=S))
+    P = np.empty((S, 2 + 18))
+    P[:, 0], P[:, 1] = p, 1.0 - p
+    P[:, 2:11] = th1[:, None]
+    P[:, 11:20] = th2[:, None]
+    sets = []
+    for size, count in ((50, 9), (90, 8)):
+        for i in range(1, count + 1):
+            _, tr = read_table(os.path.join(data, "train_%d_%d.txt" % (size, i)))
+            _, te = read_table(os.path.join(data, "test_%d_%d.txt" % (size, i)))
+            sets.append((tr[:, :9], tr[:, 9], te[:, :9]))
+    return sets, P
+
+
 def update_kernel_flops(n):
     """Algorithmic flops of the trailing-update launches for ONE matrix: tile (i,j), i > j,
     needs 2*128^3*j; a diagonal tile needs only its lower half."""
@@ -288,9 +331,51 @@ def main():
                 h.loglik_batch_dev(dX2, 64, 4, dy2, K2, dP2, B2, s22, api.MEAN_ZERO_PLUS_TAU2, 2500.0, o1, o2, o3)
             torch.cuda.synchronize()
             el2 = (time.perf_counter() - t1) / 2
-            out["secondary"] = {"workload": "cfg2: Heat-Exchanger grid, Qian n=64, 624 x 1000 evals",
-                                "value": B2 / el2, "unit": "evals/s", "ms_per_pass": 1e3 * el2,
-                                "failed_evals": int((o3 != 0).sum().item())}
+            out["secondary"] = [{"workload": "cfg2: Heat-Exchanger grid, Qian n=64, 624 x 1000 evals",
+                                 "value": B2 / el2, "unit": "evals/s", "ms_per_pass": 1e3 * el2,
+                                 "failed_evals": int((o3 != 0).sum().item())}]
+            # config 3: 2-D anisotropic grid on maximin-100 (60 x 1728 evaluations at n = 100)
+            X3, y3, P3, K3, s23 = cfg3_inputs()
+            dX3 = torch.tensor(np.asfortranarray(X3).ravel(order="F"), **f64)
+            dy3 = torch.tensor(y3, **f64)
+            dP3 = torch.tensor(np.asfortranarray(P3).ravel(order="F"), **f64)
+            B3 = P3.shape[0]
+            q1, q2 = torch.empty(B3, **f64), torch.empty(B3, **f64)
+            q3 = torch.zeros(B3, dtype=torch.int32, device=dev)
+            for it in range(3):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                h.loglik_batch_dev(dX3, 100, 2, dy3, K3, dP3, B3, s23, api.MEAN_ZERO_PLUS_TAU2, 1e4, q1, q2, q3)
+            torch.cuda.synchronize()
+            el3 = (time.perf_counter() - t1) / 2
+            out["secondary"].append({"workload": "cfg3: 2-D anisotropic grid, maximin-100, 60 x 1728 evals",
+                                     "value": B3 / el3, "unit": "evals/s", "ms_per_pass": 1e3 * el3,
+                                     "failed_evals": int((q3 != 0).sum().item())})
+            # config 5: Ground-Vibrations predictive mean/variance tables, all 17 train/test pairs
+            sets, P5 = cfg5_inputs()
+            S5 = P5.shape[0]
+            dP5 = torch.tensor(np.asfortranarray(P5).ravel(order="F"), **f64)
+            dsets, pairs = [], 0
+            for (Xs, ys, Xt) in sets:
+                m5 = Xt.shape[0]
+                pairs += S5 * m5
+                dsets.append((torch.tensor(np.asfortranarray(Xs).ravel(order="F"), **f64), torch.tensor(ys, **f64),
+                              torch.tensor(np.asfortranarray(Xt).ravel(order="F"), **f64), Xs.shape[0], m5,
+                              torch.empty(S5 * m5, **f64), torch.empty(S5 * m5, **f64), torch.empty(S5, **f64),
+                              torch.zeros(S5, dtype=torch.int32, device=dev)))
+            for it in range(3):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                for (a1, a2, a3, n5, m5, o_m, o_v, o_b, o_s) in dsets:
+                    h.predict_batch_dev(a1, n5, 9, a2, 2, dP5, S5, a3, m5, float(1.0), o_m, o_v, o_b, o_s)
+            torch.cuda.synchronize()
+            el5 = (time.perf_counter() - t1) / 2
+            out["secondary"].append({"workload": "cfg5: Ground-Vibrations predictive tables, 17 sets x 1000 draws x (150|110) test points",
+                                     "value": pairs / el5, "unit": "(draw, test point) predictions/s",
+                                     "ms_per_pass": 1e3 * el5,
+                                     "failed_draws": int(sum(int((t[8] != 0).sum().item()) for t in dsets))})
         print(json.dumps(out))
     h.close()
     if world > 1:

@@ -847,15 +847,14 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
                     BlockedWs w, double* loglik, double* beta, int* status, const BlockedJob* job) {
   const int nt = npad / kTile;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask)) {
     const void* ks[] = {(const void*)chol_update_kernel, (const void*)chol_update_s2_kernel,
                         (const void*)chol_update_s4_kernel, (const void*)chol_trsm_kernel,
                         (const void*)chol_trsm_s2_kernel, (const void*)chol_trsm_s4_kernel,
                         (const void*)rinv_tile_kernel<false>, (const void*)rinv_tile_kernel<true>};
     for (const void* k : ks)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
-    attr_set = true;
   }
   // split the nb matrices into independent groups (multiples of 8 matrices: the XCD-aware
   // block decode keeps 8 matrices per XCD group) and fork them onto the group streams

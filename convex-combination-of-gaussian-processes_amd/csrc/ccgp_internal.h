@@ -146,6 +146,17 @@ double qigamma(double p, double alpha, double beta);
 // ---- helpers -------------------------------------------------------------------------
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Kernel attributes (dynamic-LDS ceiling) are per device: a process that holds handles on several
+// GPUs must set them once on EACH.  `mask` is a function-local static, one bit per device.
+inline bool first_use_on_device(unsigned long long& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 struct ScopedTimer {
   ccgp_handle* h;
   TimedSpan* sp = nullptr;

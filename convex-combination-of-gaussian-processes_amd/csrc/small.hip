@@ -318,11 +318,10 @@ int small_pick_mtile(int n, int d, int m) {
 
 static void small_launch(hipStream_t s, const SmallArgs& a, int ndraws, int nchunks) {
   size_t lds = small_lds_bytes(a.n, a.d, a.kind == kRowsLoglik ? 0 : a.mtile);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute((const void*)small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsBytes - 64);
-    attr_set = true;
   }
   hipLaunchKernelGGL(small_kernel, dim3(ndraws, nchunks), dim3(256), lds, s, a);
 }

@@ -217,11 +217,10 @@ template <int G, int NB>
 void launch_one(hipStream_t s, const RegArgs& a) {
   constexpr int MPW = 256 / (G * G);
   const size_t lds = sizeof(double) * ((size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G));
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute((const void*)small_reg_kernel<G, NB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
-    attr_set = true;
   }
   const int kMaxGrid = 1 << 20;
   RegArgs c = a;

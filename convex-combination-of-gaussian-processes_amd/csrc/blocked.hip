@@ -29,7 +29,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kBK = 16;              // k-depth of one LDS stage
 
 struct GemmArgs {
   double* A;
@@ -65,6 +64,7 @@ struct TileGeom {
   static constexpr int CW = kTile / S;                                       // columns per workgroup
   static constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);      // 16-wide column sub-tiles per wave
   static constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);                     // 16-high row sub-tiles per wave
+  static constexpr int BK = 16;   // k-depth of one LDS stage (32 was measured 3 % slower at S = 4)
   __device__ static int row0(int wave) { return THIN ? 0 : (S == 4 ? wave * 32 : (wave >> 1) * 64); }
   __device__ static int col0(int wave) {
     return THIN ? wave * NX * 16 : (S == 4 ? 0 : (wave & 1) * (S == 1 ? 64 : 32));
@@ -80,9 +80,10 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
   constexpr int CW = TileGeom<S, THIN>::CW;
   constexpr int NX = TileGeom<S, THIN>::NX;
   constexpr int NY = TileGeom<S, THIN>::NY;
-  constexpr int STAGE = kBK * kTile + kBK * CW;        // doubles per stage, unpadded
+  constexpr int BKs = TileGeom<S, THIN>::BK;
+  constexpr int STAGE = BKs * kTile + BKs * CW;        // doubles per stage, unpadded
   constexpr int CPI = kTile / CW;                      // Q columns covered by one wave-instruction (1, 2, 4)
-  constexpr int QI = kBK / CPI / 4;                    // Q wave-instructions per wave per stage (4, 2, 1)
+  constexpr int QI = BKs / CPI / 4;                    // Q wave-instructions per wave per stage (4, 2, 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = TileGeom<S, THIN>::row0(wave);
   const int col0 = TileGeom<S, THIN>::col0(wave);
@@ -108,29 +109,29 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
 
   auto issue = [&](int stage) {
     double* Ps_ = smem + stage * STAGE + wave * kTile;          // wave-uniform LDS bases
-    double* Qs_ = smem + stage * STAGE + kBK * kTile + wave * kTile;
+    double* Qs_ = smem + stage * STAGE + BKs * kTile + wave * kTile;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < BKs / 4; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pP + q * stepP),
                                        (__attribute__((address_space(3))) void*)(Ps_ + 4 * q * kTile), 16, 0, 0);
 #pragma unroll
     for (int q = 0; q < QI; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pQ + q * stepQ),
                                        (__attribute__((address_space(3))) void*)(Qs_ + 4 * q * kTile), 16, 0, 0);
-    pP += 4 * stepP;
+    pP += (BKs / 4) * stepP;
     pQ += QI * stepQ;
   };
 
-  const int nk = Kdim / kBK;
+  const int nk = Kdim / BKs;
   issue(0);
   __syncthreads();   // drains the DMA (vmcnt(0)) and publishes it
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) issue((kt + 1) & 1);
     const double* Ps = smem + (kt & 1) * STAGE;
-    const double* Qs = Ps + kBK * kTile;
+    const double* Qs = Ps + BKs * kTile;
     const int sw = l4 & 1;   // k parity of this lane's fragment element (k = 4 kk + l4)
 #pragma unroll
-    for (int kk = 0; kk < kBK / 4; ++kk) {
+    for (int kk = 0; kk < BKs / 4; ++kk) {
       double pf[NY], qf[NX];
 #pragma unroll
       for (int y = 0; y < NY; ++y)
@@ -163,23 +164,32 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
   const int row0 = TileGeom<S, THIN>::row0(wave), col0 = TileGeom<S, THIN>::col0(wave);
   const int l15 = lane & 15, l4 = lane >> 4;
   if (THIN && col0 >= TileGeom<S, THIN>::CW) return;
+  // all loads of one 16-column group are issued before the first store: written as
+  // `*p = *p - acc` the compiler orders every load behind the previous store and the epilogue
+  // becomes 16-64 serial memory round trips per thread
 #pragma unroll
-  for (int x = 0; x < NX; ++x)
+  for (int x = 0; x < NX; ++x) {
+    double cv[NY][4];
+    if (mode == 0) {
+#pragma unroll
+      for (int y = 0; y < NY; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cv[y][r] = C[row0 + y * 16 + l15 + (size_t)(col0 + x * 16 + l4 + 4 * r) * ld];
+    }
 #pragma unroll
     for (int y = 0; y < NY; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int col = col0 + x * 16 + l4 + 4 * r;
-        const int row = row0 + y * 16 + l15;
-        double* p = C + row + (size_t)col * ld;
-        if (mode == 0) *p = *p - acc[x][y][r];
-        else *p = acc[x][y][r];
+        double* p = C + row0 + y * 16 + l15 + (size_t)(col0 + x * 16 + l4 + 4 * r) * ld;
+        *p = mode == 0 ? cv[y][r] - acc[x][y][r] : acc[x][y][r];
       }
+  }
 }
 
 template <int S>
 constexpr size_t gemm_lds_bytes() {
-  return sizeof(double) * 2 * (kBK * kTile + kBK * (kTile / S));   // two unpadded stages
+  return sizeof(double) * 2 * TileGeom<S, false>::BK * (kTile + kTile / S);   // two unpadded stages
 }
 
 template <int MODE, int S>

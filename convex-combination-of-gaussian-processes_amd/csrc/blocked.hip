@@ -73,10 +73,21 @@ struct TileGeom {
 
 // acc[x][y] += (Q strip)(P tile)' over Kdim: accumulator register r of sub-tile (x, y) is element
 // (row0 + 16y + lane&15, col0 + 16x + (lane>>4) + 4r) of the 128 x CW output.
-template <int S, bool THIN>
+// TRI (trsm only, S = 1): Q = W_j is LOWER triangular (W[c][k] = 0 for k > c), so the 16-column
+// sub-tile cb contributes nothing once the stage index kt exceeds cb; those MFMAs are skipped,
+// and the sub-tiles are dealt to the two wave columns interleaved (cb = wn + 2x) so that both
+// keep a similar share of the surviving work (20 and 16 of 32 units instead of 26 and 10).
+template <int S, bool THIN, bool TRI>
+__device__ __forceinline__ int col_block(int wave, int x) {
+  if constexpr (TRI && !THIN) return (wave & 1) + 2 * x;
+  else return (TileGeom<S, THIN>::col0(wave) >> 4) + x;
+}
+
+template <int S, bool THIN, bool TRI = false>
 __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, int ldP, const double* Q,
                                                 int ldQ, int Kdim,
                                                 d4 (&acc)[TileGeom<S, THIN>::NX][TileGeom<S, THIN>::NY]) {
+  static_assert(!TRI || S == 1, "the triangular skip is only wired for full-width tiles");
   constexpr int CW = TileGeom<S, THIN>::CW;
   constexpr int NX = TileGeom<S, THIN>::NX;
   constexpr int NY = TileGeom<S, THIN>::NY;
@@ -138,13 +149,15 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
         pf[y] = Ps[(kk * 4 + l4) * kTile + ((((row0 >> 4) + y) ^ sw) << 4) + l15];
 #pragma unroll
       for (int x = 0; x < NX; ++x)
-        qf[x] = Qs[(kk * 4 + l4) * CW + ((((col0 >> 4) + x) ^ sw) << 4) + l15];
+        qf[x] = Qs[(kk * 4 + l4) * CW + ((col_block<S, THIN, TRI>(wave, x) ^ sw) << 4) + l15];
       if (active) {
 #pragma unroll
-        for (int x = 0; x < NX; ++x)
+        for (int x = 0; x < NX; ++x) {
+          if (TRI && col_block<S, THIN, TRI>(wave, x) < kt) continue;   // wave-uniform: zero block of W
 #pragma unroll
           for (int y = 0; y < NY; ++y)
             acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[x], pf[y], acc[x][y], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -153,13 +166,13 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
 }
 
 // C = C - acc (mode 0) or C = acc (mode 1) for one strip.
-template <int S, bool THIN>
+template <int S, bool THIN, bool TRI = false>
 __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
                                           int ldQ, int Kdim, double* C, int ld, int mode) {
   constexpr int NX = TileGeom<S, THIN>::NX;
   constexpr int NY = TileGeom<S, THIN>::NY;
   d4 acc[NX][NY];
-  gemm_accumulate<S, THIN>(smem, P, ldP, Q, ldQ, Kdim, acc);
+  gemm_accumulate<S, THIN, TRI>(smem, P, ldP, Q, ldQ, Kdim, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = TileGeom<S, THIN>::row0(wave), col0 = TileGeom<S, THIN>::col0(wave);
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -175,13 +188,13 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
       for (int y = 0; y < NY; ++y)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cv[y][r] = C[row0 + y * 16 + l15 + (size_t)(col0 + x * 16 + l4 + 4 * r) * ld];
+          cv[y][r] = C[row0 + y * 16 + l15 + (size_t)(col_block<S, THIN, TRI>(wave, x) * 16 + l4 + 4 * r) * ld];
     }
 #pragma unroll
     for (int y = 0; y < NY; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double* p = C + row0 + y * 16 + l15 + (size_t)(col0 + x * 16 + l4 + 4 * r) * ld;
+        double* p = C + row0 + y * 16 + l15 + (size_t)(col_block<S, THIN, TRI>(wave, x) * 16 + l4 + 4 * r) * ld;
         *p = mode == 0 ? cv[y][r] - acc[x][y][r] : acc[x][y][r];
       }
   }
@@ -236,8 +249,9 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
     Kdim = kTile;
   }
   double* C = Ab + (size_t)i * kTile + ((size_t)g.j * kTile + c0) * ld;
-  if (thin) gemm_tile<S, true>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
-  else gemm_tile<S, false>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
+  constexpr bool TRI = MODE == 1 && S == 1;   // trsm: Q is the lower-triangular inverse block
+  if (thin) gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
+  else gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
 }
 
 // distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
@@ -255,12 +269,12 @@ CCGP_DEFINE_GEMM(chol_trsm_s4_kernel, 1, 4, 3)
 #undef CCGP_DEFINE_GEMM
 
 // Strip count for an update launch: minimise ceil(workgroups / resident slots) x time per
-// workgroup.  Slots per chip (2 / 2 / 3 workgroups per CU by LDS) and the relative per-flop
-// efficiency of the narrower strips (1 / 0.85 / 0.70) were fitted to per-launch rocprof
-// timings on MI355X (profiles/r01c_strip_selection.md): within 0.5 % of the per-launch optimum.
+// workgroup.  Slots per chip (2 / 3 / 3 workgroups per CU by LDS) and the relative per-flop
+// efficiency of the narrower strips (1 / 0.80 / 0.65) were fitted to per-launch rocprof
+// timings on MI355X (profiles/r01c_strip_selection.md): within 1.3 % of the per-launch optimum.
 static int pick_strips(int tiles) {
-  const int slots[3] = {512, 512, 768};
-  const double eff[3] = {1.0, 0.85, 0.70};
+  const int slots[3] = {512, 768, 768};
+  const double eff[3] = {1.0, 0.80, 0.65};
   int best = 1;
   double best_cost = 1e300;
   for (int q = 0; q < 3; ++q) {

@@ -778,41 +778,64 @@ BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
 }
 
 // One matrix group's whole sweep, enqueued on stream s.  w is already offset to the group.
-static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n, int d, const double* y,
-                          DrawView dv, int b0, int nb, int npad, double sigma2, int mean_mode,
-                          double tau2, BlockedWs w, double* loglik, double* beta, int* status,
-                          const BlockedJob* job) {
-  const BlockedJob* pr = job && job->kind == kJobPredict ? job : nullptr;
-  const int nt = npad / kTile;
-  {
-    ScopedTimer t(h, CCGP_T_COV, s);
-    launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld);
-    RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
-    hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
-    if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site
-      launch_cov_cross_batched(s, pr->Xtest, pr->m, X, n, d, dv, b0, nb, w.A + npad + kTile, w.a_stride,
-                               w.ld);
-  }
+// One chunk's sweep (all matrices advance together), split into its phases.
+struct GroupRun {
+  ccgp_handle* h;
+  hipStream_t s;
+  const double* X;
+  int n, d;
+  const double* y;
+  DrawView dv;
+  int b0, nb, npad, nt;
+  double sigma2;
+  int mean_mode;
+  double tau2;
+  BlockedWs w;
+  double* loglik;
+  double* beta;
+  int* status;
+  const BlockedJob* job;
   GemmArgs g{};
-  g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
-  g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb; g.ld = w.ld; g.ne = w.ne;
-  g.extra_lower = job && job->kind >= kJobInverse ? 1 : 0;
   DiagArgs dg{};
-  dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
-  dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
-  dg.nb = nb; dg.n = n; dg.ld = w.ld;
-  static int force_s = -1;   // CCGP_STRIPS=1|2|4 pins the strip count (profiling only)
-  if (force_s < 0) {
-    const char* e = getenv("CCGP_STRIPS");
-    force_s = e ? atoi(e) : 0;
-  }
-  for (int j = 0; j < nt; ++j) {
-    g.j = j;
-    if (j > 0) {
-      ScopedTimer t(h, CCGP_T_UPDATE, s);
-      g.mode = 0;
-      launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8) * (nt - j + 1 + w.ne)));
+  int force_s = 0;
+
+  void begin() {
+    const BlockedJob* pr = job && job->kind == kJobPredict ? job : nullptr;
+    nt = npad / kTile;
+    {
+      ScopedTimer t(h, CCGP_T_COV, s);
+      launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld);
+      RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
+      hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
+      if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site
+        launch_cov_cross_batched(s, pr->Xtest, pr->m, X, n, d, dv, b0, nb, w.A + npad + kTile, w.a_stride,
+                                 w.ld);
     }
+    g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
+    g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb; g.ld = w.ld; g.ne = w.ne;
+    g.extra_lower = job && job->kind >= kJobInverse ? 1 : 0;
+    dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
+    dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
+    dg.nb = nb; dg.n = n; dg.ld = w.ld;
+    static int env_s = -1;   // CCGP_STRIPS=1|2|4 pins the strip count (profiling only)
+    if (env_s < 0) {
+      const char* e = getenv("CCGP_STRIPS");
+      env_s = e ? atoi(e) : 0;
+    }
+    force_s = env_s;
+  }
+
+  // T_ij = A_ij - sum_{k<j} L_ik L_jk' for every tile row of block column j (nothing to do at j = 0)
+  void update(int j) {
+    if (j == 0) return;
+    ScopedTimer t(h, CCGP_T_UPDATE, s);
+    g.j = j;
+    g.mode = 0;
+    launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8) * (nt - j + 1 + w.ne)));
+  }
+
+  // L_jj, W_j = L_jj^-1, then L_ij = T_ij W_j' for the rows below
+  void panel(int j) {
     {
       ScopedTimer t(h, CCGP_T_DIAG, s);
       dg.j = j;
@@ -820,46 +843,60 @@ static void blocked_group(ccgp_handle* h, hipStream_t s, const double* X, int n,
     }
     {
       ScopedTimer t(h, CCGP_T_TRSM, s);
+      g.j = j;
       g.mode = 1;
       launch_gemm(s, g, 1, 1);   // trsm is in place: strips of one tile would race (read-all / write-own)
     }
   }
-  {
-    ScopedTimer t(h, CCGP_T_SOLVE, s);
-    FinishArgs fa{};
-    fa.A = w.A; fa.a_stride = w.a_stride; fa.npad = npad; fa.logdet_part = w.z; fa.params = dv.params;
-    fa.ldp = dv.ldp; fa.K = dv.K; fa.b0 = b0; fa.nt = nt; fa.n = n; fa.sigma2 = sigma2;
-    fa.mode = mean_mode; fa.loglik = loglik; fa.beta = beta; fa.status = status; fa.ld = w.ld;
-    fa.s11_out = w.fin; fa.beta_out = w.fin + nb;
-    hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, s, fa);
-    if (pr) {
-      PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, pr->m, w.fin, w.fin + nb, status, b0, pr->S,
-                        sigma2, pr->mean, pr->var};
-      hipLaunchKernelGGL(predict_finish_kernel, dim3((pr->m + 255) / 256, nb), dim3(256), 0, s, pa);
+
+  void finish() {
+    const BlockedJob* pr = job && job->kind == kJobPredict ? job : nullptr;
+    {
+      ScopedTimer t(h, CCGP_T_SOLVE, s);
+      FinishArgs fa{};
+      fa.A = w.A; fa.a_stride = w.a_stride; fa.npad = npad; fa.logdet_part = w.z; fa.params = dv.params;
+      fa.ldp = dv.ldp; fa.K = dv.K; fa.b0 = b0; fa.nt = nt; fa.n = n; fa.sigma2 = sigma2;
+      fa.mode = mean_mode; fa.loglik = loglik; fa.beta = beta; fa.status = status; fa.ld = w.ld;
+      fa.s11_out = w.fin; fa.beta_out = w.fin + nb;
+      hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, s, fa);
+      if (pr) {
+        PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, pr->m, w.fin, w.fin + nb, status, b0, pr->S,
+                          sigma2, pr->mean, pr->var};
+        hipLaunchKernelGGL(predict_finish_kernel, dim3((pr->m + 255) / 256, nb), dim3(256), 0, s, pa);
+      }
+    }
+    if (job && job->kind >= kJobInverse) {
+      ScopedTimer t(h, CCGP_T_SOLVE, s);
+      const int ntiles = nt * (nt + 1) / 2;
+      RinvArgs ra{};
+      ra.A = w.A; ra.a_stride = w.a_stride; ra.npad = npad; ra.ld = w.ld; ra.nt = nt; ra.n = n; ra.nb = nb;
+      const dim3 grid(round_up(nb, 8) * ntiles), block(256);
+      if (job->kind == kJobInverse) {
+        ra.Rinv = job->Rinv;
+        hipLaunchKernelGGL(rinv_tile_kernel<false>, grid, block, gemm_lds_bytes<1>(), s, ra);
+      } else {
+        const int P = dv.K + dv.K * d;
+        AlphaArgs aa{w.A, w.a_stride, npad, w.ld, n, w.fin + nb, job->alpha};
+        hipLaunchKernelGGL(alpha_kernel, dim3((npad + 255) / 256, nb), dim3(256), 0, s, aa);
+        ra.X = X; ra.d = d; ra.K = dv.K; ra.params = dv.params; ra.ldp = dv.ldp; ra.draw0 = b0;
+        ra.sigma2 = sigma2; ra.alpha = job->alpha; ra.gpart = job->gpart;
+        hipLaunchKernelGGL(rinv_tile_kernel<true>, grid, block, gemm_lds_bytes<1>(), s, ra);
+        GradReduceArgs ga{job->gpart, ntiles, P, dv.K, d, nb, b0, job->Btot, dv.params, dv.ldp, sigma2,
+                          status, job->grad};
+        hipLaunchKernelGGL(blocked_grad_reduce_kernel, dim3((nb * P + 255) / 256), dim3(256), 0, s, ga);
+      }
     }
   }
-  if (job && job->kind >= kJobInverse) {
-    ScopedTimer t(h, CCGP_T_SOLVE, s);
-    const int ntiles = nt * (nt + 1) / 2;
-    RinvArgs ra{};
-    ra.A = w.A; ra.a_stride = w.a_stride; ra.npad = npad; ra.ld = w.ld; ra.nt = nt; ra.n = n; ra.nb = nb;
-    const dim3 grid(round_up(nb, 8) * ntiles), block(256);
-    if (job->kind == kJobInverse) {
-      ra.Rinv = job->Rinv;
-      hipLaunchKernelGGL(rinv_tile_kernel<false>, grid, block, gemm_lds_bytes<1>(), s, ra);
-    } else {
-      const int P = dv.K + dv.K * d;
-      AlphaArgs aa{w.A, w.a_stride, npad, w.ld, n, w.fin + nb, job->alpha};
-      hipLaunchKernelGGL(alpha_kernel, dim3((npad + 255) / 256, nb), dim3(256), 0, s, aa);
-      ra.X = X; ra.d = d; ra.K = dv.K; ra.params = dv.params; ra.ldp = dv.ldp; ra.draw0 = b0;
-      ra.sigma2 = sigma2; ra.alpha = job->alpha; ra.gpart = job->gpart;
-      hipLaunchKernelGGL(rinv_tile_kernel<true>, grid, block, gemm_lds_bytes<1>(), s, ra);
-      GradReduceArgs ga{job->gpart, ntiles, P, dv.K, d, nb, b0, job->Btot, dv.params, dv.ldp, sigma2,
-                        status, job->grad};
-      hipLaunchKernelGGL(blocked_grad_reduce_kernel, dim3((nb * P + 255) / 256), dim3(256), 0, s, ga);
+
+  void run_all() {
+    begin();
+    for (int j = 0; j < nt; ++j) {
+      update(j);
+      panel(j);
     }
+    finish();
   }
-}
+};
 
 // LDS scratch of the gradient contraction must fit the S = 1 staging area
 bool blocked_grad_supported(int d, int K) {
@@ -870,7 +907,6 @@ bool blocked_grad_supported(int d, int K) {
 void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
                     BlockedWs w, double* loglik, double* beta, int* status, const BlockedJob* job) {
-  const int nt = npad / kTile;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
     const void* ks[] = {(const void*)chol_update_kernel, (const void*)chol_update_s2_kernel,
@@ -880,33 +916,16 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
     for (const void* k : ks)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
   }
-  // split the nb matrices into independent groups (multiples of 8 matrices: the XCD-aware
-  // block decode keeps 8 matrices per XCD group) and fork them onto the group streams
-  int ng = h->n_groups;
-  if (job && job->kind >= kJobInverse) ng = 1;   // their scratch is addressed per chunk, not per group
-  if (ng > nb / 8) ng = nb / 8;
-  if (ng < 1) ng = 1;
-  if (ng == 1) {
-    blocked_group(h, h->stream, X, n, d, y, dv, b0, nb, npad, sigma2, mean_mode, tau2, w, loglik, beta,
-                  status, job);
-    return;
-  }
-  (void)hipEventRecord(h->fork, h->stream);
-  const int per = round_up((nb + ng - 1) / ng, 8);
-  for (int gidx = 0, m0 = 0; m0 < nb; ++gidx, m0 += per) {
-    const int cnt = (nb - m0) < per ? (nb - m0) : per;
-    hipStream_t s = h->gstream[gidx];
-    (void)hipStreamWaitEvent(s, h->fork, 0);
-    BlockedWs wg = w;
-    wg.A = w.A + (size_t)m0 * w.a_stride;
-    wg.invd = w.invd + (size_t)m0 * nt * kTile * kTile;
-    wg.z = w.z + (size_t)m0 * nt;
-    wg.fin = w.fin + (size_t)2 * m0;   // (s11, beta) pairs are addressed as fin[0..cnt) and fin[cnt..2cnt)
-    blocked_group(h, s, X, n, d, y, dv, b0 + m0, cnt, npad, sigma2, mean_mode, tau2, wg, loglik, beta,
-                  status, job);
-    (void)hipEventRecord(h->gjoin[gidx], s);
-    (void)hipStreamWaitEvent(h->stream, h->gjoin[gidx], 0);
-  }
+  GroupRun r{};
+  r.h = h; r.s = h->stream; r.X = X; r.n = n; r.d = d; r.y = y; r.dv = dv; r.b0 = b0; r.nb = nb;
+  r.npad = npad; r.sigma2 = sigma2; r.mean_mode = mean_mode; r.tau2 = tau2; r.w = w;
+  r.loglik = loglik; r.beta = beta; r.status = status; r.job = job;
+  // All matrices of the chunk advance together on one stream.  Splitting the batch into groups on
+  // separate streams was measured and rejected twice (profiles/r01c_strip_selection.md): free-running
+  // groups (+4 % at 2 groups, slower at 4+) and an event-ordered two-group ping-pong that hides
+  // diag / trsm underneath the other half's update (33.9 vs 33.8 ms: the half-size update launches
+  // lose to wave quantisation what the overlap gains).
+  r.run_all();
 }
 
 }  // namespace ccgp

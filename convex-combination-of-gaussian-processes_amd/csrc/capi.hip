@@ -249,18 +249,6 @@ int ccgp_create(int device, ccgp_handle** out) {
     return CCGP_EHIP;
   }
   h->stream = h->own_stream;
-  bool ok = hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < ccgp_handle::kMaxGroups && ok; ++i)
-    ok = hipStreamCreateWithFlags(&h->gstream[i], hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&h->gjoin[i], hipEventDisableTiming) == hipSuccess;
-  if (!ok) {
-    ccgp_destroy(h);
-    return CCGP_EHIP;
-  }
-  if (const char* e = getenv("CCGP_GROUPS")) {
-    int v = atoi(e);
-    if (v >= 1 && v <= ccgp_handle::kMaxGroups) h->n_groups = v;
-  }
   *out = h;
   return CCGP_OK;
 }
@@ -273,11 +261,6 @@ int ccgp_destroy(ccgp_handle* h) {
     (void)hipEventDestroy(s.e0);
     (void)hipEventDestroy(s.e1);
   }
-  for (int i = 0; i < ccgp_handle::kMaxGroups; ++i) {
-    if (h->gstream[i]) { (void)hipStreamSynchronize(h->gstream[i]); (void)hipStreamDestroy(h->gstream[i]); }
-    if (h->gjoin[i]) (void)hipEventDestroy(h->gjoin[i]);
-  }
-  if (h->fork) (void)hipEventDestroy(h->fork);
   if (h->ws) (void)hipFree(h->ws);
   if (h->stage) (void)hipFree(h->stage);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

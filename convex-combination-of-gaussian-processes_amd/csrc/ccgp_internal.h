@@ -42,13 +42,6 @@ struct ccgp_handle {
   bool timing = false;
   std::vector<ccgp::TimedSpan> spans;
   size_t spans_used = 0;
-  // independent matrix groups of the blocked path run on their own streams so that one
-  // group's partially filled last wave of workgroups overlaps another group's launches
-  static constexpr int kMaxGroups = 8;
-  int n_groups = 1;  // measured on MI355X / ROCm 7.2: 2 groups +4 %, 4+ groups slower (CCGP_GROUPS overrides)
-  hipStream_t gstream[kMaxGroups] = {};
-  hipEvent_t gjoin[kMaxGroups] = {};
-  hipEvent_t fork = nullptr;
 };
 
 namespace ccgp {

@@ -48,6 +48,7 @@ SIGNATURES = {
                              _dp, _dp, _ip]),
     "ccgp_grid_marginal": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_double, _dp, c_int, c_int,
                                    c_double, c_int, c_double, _dp, _ip, _dp]),
+    "ccgp_mixed_logdet_designs": (c_int, [c_void_p, _dp, c_int, c_int, c_int, c_int, _dp, _dp, _ip]),
     "ccgp_halton_base2": (c_int, [c_int, _dp]),
     "ccgp_qigamma": (c_int, [_dp, c_int, c_double, c_double, _dp]),
     "ccgp_predict_batch": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_int, _dp, c_int, _dp, c_int,
@@ -293,6 +294,18 @@ class Handle:
                                            int(N), float(tau), 1 if take_log else 0,
                                            float(aniso_lambda), _p(out), ctypes.byref(arg), _p(logs)))
         return (out, arg.value, logs) if want_logs else (out, arg.value)
+
+    # -- 8(f)-4: entropy criteria ------------------------------------------------------------
+    def mixed_logdet_designs(self, designs, K, params_row):
+        """designs: [B, n, d] candidate designs sharing one parameter row -> (logdet[B], status[B])."""
+        designs = np.asarray(designs, dtype=np.float64)
+        B, n, d = designs.shape
+        Xs = np.ascontiguousarray(np.stack([np.asfortranarray(D).ravel(order="F") for D in designs]))
+        row = _f(params_row, (K + K * d,))
+        out = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        self._chk(lib().ccgp_mixed_logdet_designs(self._h, _p(Xs), n, d, B, K, _p(row), _p(out), _ipt(st)))
+        return out, st
 
     # -- a10 + a11 -------------------------------------------------------------------------
     def predict_batch(self, X, y, K, params, Xtest, sigma2):

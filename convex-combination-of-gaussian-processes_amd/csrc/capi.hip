@@ -710,6 +710,41 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   return st != 0 ? 1 : 0;
 }
 
+// ---- 8(f)-4: entropy criteria over candidate designs ------------------------------------------------
+int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, int B, int K,
+                              const double* params, double* out_logdet, int* status) {
+  if (!h) return CCGP_EINVAL;
+  if (bad_shape(n, d, K) || B < 1 || !Xs || !params || !out_logdet)
+    return fail(h, CCGP_EINVAL, "ccgp_mixed_logdet_designs: bad argument");
+  if (!small_reg_supported(n, d, true))
+    return fail(h, CCGP_EUNSUPPORTED, "ccgp_mixed_logdet_designs: designs of more than 128 points (or too wide for LDS) not implemented");
+  CCGP_HIP(hipSetDevice(h->device));
+  const int P = K + K * d;
+  size_t need = Carver::al(sizeof(double) * (size_t)B * n * d) + Carver::al(sizeof(double) * P) +
+                Carver::al(sizeof(double) * B) + Carver::al(sizeof(int) * (size_t)B);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dXs = c.take<double>((size_t)B * n * d);
+  double* dp = c.take<double>(P);
+  double* dld = c.take<double>(B);
+  int* dst = c.take<int>(B);
+  CCGP_HIP(hipMemcpyAsync(dXs, Xs, sizeof(double) * (size_t)B * n * d, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+  DrawView dv{dp, 1, K, d};
+  {
+    ScopedTimer t(h, CCGP_T_FUSED);
+    launch_small_reg_logdet_designs(h->stream, dXs, n, d, dv, B, dld, dst);
+  }
+  CCGP_HIP(hipGetLastError());
+  std::vector<int> st(B);
+  CCGP_HIP(hipMemcpyAsync(out_logdet, dld, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
+  return count_bad(st.data(), B);
+}
+
 // ---- a9: hyperprior grid ------------------------------------------------------------------------
 int ccgp_halton_base2(int N, double* out) {
   if (N < 0 || !out) return CCGP_EINVAL;

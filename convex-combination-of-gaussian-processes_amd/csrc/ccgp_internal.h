@@ -89,7 +89,9 @@ void launch_small_grad(hipStream_t s, const double* X, int n, int d, const doubl
                        int* status, double* gpart);
 
 // ---- small_reg.hip: register-resident evaluator for the plain likelihood (n <= 128) ---------
-bool small_reg_supported(int n, int d);
+bool small_reg_supported(int n, int d, bool per_design = false);
+void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int d, DrawView dv, int B,
+                                     double* logdet, int* status);
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                              int B, double sigma2, int mean_mode, double tau2, double* loglik,
                              double* beta, int* status);

@@ -35,6 +35,11 @@ struct RegArgs {
   double* loglik;
   double* beta;
   int* status;
+  // design-batched form (entropy criteria, BSQ:856-877): every evaluation has its OWN design
+  // (X + b * x_stride) and all share one parameter row; only log det R_mixed is wanted
+  size_t x_stride;     // 0: one shared design
+  int shared_params;   // 1: params is a single row
+  double* logdet;      // optional output: sum_k log d_k
 };
 
 constexpr int kPerMat(int NP, int G) {  // doubles of LDS per matrix
@@ -77,10 +82,17 @@ __global__ __launch_bounds__(256) void small_reg_kernel(RegArgs a) {
   double* dvec = colbuf + 2 * (NP + G);
   double* zb = dvec + NP;                     // [2][NP]
 
-  for (int e = tid; e < n * d; e += 256) xs[e] = a.X[e];
-  for (int e = lt; e < K * d; e += TPM) th[e] = a.params[b + (size_t)(K + e) * a.ldp];
+  const int pb = a.shared_params ? 0 : b;
+  if (a.x_stride == 0) {
+    for (int e = tid; e < n * d; e += 256) xs[e] = a.X[e];
+  } else {
+    // per-evaluation designs: each matrix keeps its own copy right behind the shared slot
+    xs = smem + (size_t)d * n + (size_t)MPW * PM + (size_t)sub * d * n;
+    for (int e = lt; e < n * d; e += TPM) xs[e] = a.X[(size_t)b * a.x_stride + e];
+  }
+  for (int e = lt; e < K * d; e += TPM) th[e] = a.params[pb + (size_t)(K + e) * a.ldp];
   if (lt < K) {
-    const double w = a.params[b + (size_t)lt * a.ldp];
+    const double w = a.params[pb + (size_t)lt * a.ldp];
     w2[lt] = w * w;
   }
   __syncthreads();
@@ -206,9 +218,10 @@ __global__ __launch_bounds__(256) void small_reg_kernel(RegArgs a) {
     }
     if (bad) { ll = kNaN; beta = kNaN; }
     if (lt == 0 && valid) {
-      a.loglik[b] = ll;
+      if (a.loglik) a.loglik[b] = ll;
       if (a.beta) a.beta[b] = beta;
       if (a.status) a.status[b] = bad;
+      if (a.logdet) a.logdet[b] = bad ? kNaN : logdet;
     }
   }
 }
@@ -216,7 +229,8 @@ __global__ __launch_bounds__(256) void small_reg_kernel(RegArgs a) {
 template <int G, int NB>
 void launch_one(hipStream_t s, const RegArgs& a) {
   constexpr int MPW = 256 / (G * G);
-  const size_t lds = sizeof(double) * ((size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G));
+  const size_t lds = sizeof(double) * ((size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G) +
+                                       (a.x_stride ? (size_t)MPW * a.d * a.n : 0));
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute((const void*)small_reg_kernel<G, NB>,
@@ -233,13 +247,16 @@ void launch_one(hipStream_t s, const RegArgs& a) {
 
 }  // namespace
 
-bool small_reg_supported(int n, int d) {
+bool small_reg_supported(int n, int d, bool per_design) {
   if (n > 128) return false;
   const int G = n <= 64 ? 8 : 16;
   const int NB = (n + G - 1) / G;
   const int MPW = 256 / (G * G);
-  return sizeof(double) * ((size_t)d * n + (size_t)MPW * kPerMat(G * NB, G)) <= (size_t)kLdsBytes - 64;
+  return sizeof(double) * ((size_t)d * n + (size_t)MPW * kPerMat(G * NB, G) +
+                           (per_design ? (size_t)MPW * d * n : 0)) <= (size_t)kLdsBytes - 64;
 }
+
+static void dispatch(hipStream_t s, const RegArgs& a);
 
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                              int B, double sigma2, int mean_mode, double tau2, double* loglik,
@@ -248,6 +265,24 @@ void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const
   a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
   a.draw0 = 0; a.B = B; a.sigma2 = sigma2; a.mode = mean_mode; a.tau2 = tau2;
   a.loglik = loglik; a.beta = beta; a.status = status;
+  dispatch(s, a);
+}
+
+// log det R_mixed for B candidate designs (Xs = B blocks of n x d, column-major each) under ONE
+// parameter row: Entropy = -det(R) (BSQ:856-861), Augmented.Mixed.Entropy = -det(R_all)/det(R_old)
+// (BSQ:869-877, Schur complement).
+void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int d, DrawView dv, int B,
+                                     double* logdet, int* status) {
+  RegArgs a{};
+  a.X = Xs; a.y = Xs;   // the right-hand-side row is not used; any n readable doubles will do
+  a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
+  a.draw0 = 0; a.B = B; a.sigma2 = 1.0; a.mode = 0; a.tau2 = 0.0;
+  a.status = status; a.x_stride = (size_t)n * d; a.shared_params = 1; a.logdet = logdet;
+  dispatch(s, a);
+}
+
+static void dispatch(hipStream_t s, const RegArgs& a) {
+  const int n = a.n;
   if (n <= 64) {
     switch ((n + 7) / 8) {
       case 1: launch_one<8, 1>(s, a); break;

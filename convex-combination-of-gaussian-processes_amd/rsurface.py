@@ -160,6 +160,29 @@ class CombinedGP:
         mean, var = self.h.predict_from_factors(r.reshape(1, -1), beta, mf, v1, v2, R_Inv, sigma2)
         return np.array([[mean[0], var[0]]])
 
+    # ------------------------------------------------------------------ entropy criteria (BSQ)
+    def Entropy(self, D, p, theta1, theta2):
+        """Batch Sequential ME Design.R:856-861: -det(Mixed.corr.matrix(D, p, theta1, theta2))."""
+        return float(self.Entropy_batch(np.asarray(D, dtype=np.float64)[None], p, theta1, theta2)[0])
+
+    def Entropy_batch(self, designs, p, theta1, theta2):
+        """Entropy for many candidate designs [B, n, d] in one device call (what the multi-start
+        L-BFGS-B of Entropy.optim, BSQ:886-912, evaluates one at a time)."""
+        designs = np.asarray(designs, dtype=np.float64)
+        ld, st = self.h.mixed_logdet_designs(designs, 2, pack_iso(p, theta1, theta2, designs.shape[2]))
+        return np.where(st == 0, -np.exp(ld), np.nan)
+
+    def Augmented_Mixed_Entropy(self, D_old, D_new, p, theta1, theta2, R_old_Inv=None):
+        """BSQ:869-877: -det(R.new - R.cross R.old^-1 R.cross').  Computed as
+        -det(R(D.old U D.new)) / det(R(D.old)) (Schur complement), so R.old.Inv is not needed."""
+        D_old, D_new = np.asarray(D_old, dtype=np.float64), np.asarray(D_new, dtype=np.float64)
+        row = pack_iso(p, theta1, theta2, D_old.shape[1])
+        ld_all, s1 = self.h.mixed_logdet_designs(np.vstack([D_old, D_new])[None], 2, row)
+        ld_old, s2 = self.h.mixed_logdet_designs(D_old[None], 2, row)
+        if s1[0] or s2[0]:
+            return float("nan")
+        return -float(np.exp(ld_all[0] - ld_old[0]))
+
     # ------------------------------------------------------------------ batched forms
     def draws_to_params(self, D_train, draws):
         """draws rows (p, theta1, theta2[, lambda]) -> C-ABI parameter matrix."""

@@ -168,6 +168,15 @@ int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, dou
                               double var_factor2, const double* R_inv, double sigma2,
                               double* out_mean, double* out_var);
 
+/* ---- entropy criteria of the batch-sequential design script ---------------------------
+ * Entropy(D, p, theta1, theta2) = -det(R.mixed(D))  (Batch Sequential ME Design.R:856-861) and
+ * Augmented.Mixed.Entropy = -det(R.new - R.cross R.old^-1 R.cross') (same file :869-877), which by
+ * the Schur complement equals -det(R.mixed(D.old U D.new)) / det(R.mixed(D.old)): both are log
+ * determinants of the mixed correlation matrix of a CANDIDATE DESIGN.  Xs holds B designs of
+ * n x d (column-major each, design b at Xs + b*n*d) that share ONE parameter row; n <= 128. */
+int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, int B, int K,
+                              const double* params, double* out_logdet, int* status);
+
 /* ---- measurement hooks (bench.py / rocprof; not part of the R surface) ---------------
  * Time, with HIP events on the handle's stream, every launch group of the most recent
  * *_dev call: ids below.  Returns milliseconds summed over launches and the count. */

@@ -411,6 +411,31 @@ def loglik_grad_fd(X, y, row, K, d, sigma2, h=1e-6):
     return g
 
 
+# --------------------------------------------------------------------------- entropy criteria (8(f)-4)
+def cross_corr_matrix(D_old, D_new, theta):
+    """BSQ:835-848: exp(-(U + V + W)), n.new x n.old, isotropic."""
+    D_old, D_new = np.asarray(D_old, dtype=np.float64), np.asarray(D_new, dtype=np.float64)
+    d = D_new.shape[1]
+    Theta = np.diag(np.full(d, float(theta)))
+    U = ((D_new ** 2) @ Theta).sum(axis=1)[:, None]
+    V = -2.0 * ((D_new @ Theta) @ D_old.T)
+    W = ((D_old ** 2) @ Theta).sum(axis=1)[None, :]
+    return np.exp(-((U + V) + W))
+
+
+def entropy(D, p, theta1, theta2):
+    """BSQ:856-861: -det(R.mixed)."""
+    return -float(np.linalg.det(mixed_corr_matrix_iso(D, p, theta1, theta2)))
+
+
+def augmented_mixed_entropy(D_old, D_new, p, theta1, theta2):
+    """BSQ:869-877 with R.old.Inv = solve(R.old) as in Batch.Entropy.optim (BSQ:924-925)."""
+    R_old_inv = solve_inverse(mixed_corr_matrix_iso(D_old, p, theta1, theta2))
+    R_cross = _mix(p, cross_corr_matrix(D_old, D_new, theta1), cross_corr_matrix(D_old, D_new, theta2))
+    R_new = mixed_corr_matrix_iso(D_new, p, theta1, theta2)
+    return -float(np.linalg.det(R_new - (R_cross @ R_old_inv) @ R_cross.T))
+
+
 # --------------------------------------------------------------------------- config 1 (CPU plumbing)
 def matern_corr(nu, h, theta):
     """D1:348-351: (2 sqrt(nu)|h|/theta)^nu K_nu(2 sqrt(nu)|h|/theta) / (Gamma(nu) 2^(nu-1)),

@@ -114,3 +114,15 @@ ccgp.prediction.table <- function(D.test, draws, D.train, sigma2, y.train) {
              as.matrix(D.test), as.double(sigma2))
   list(mean = r[[1]], var = r[[2]], beta = r[[3]])
 }
+
+# Entropy criteria of the batch-sequential design script (Batch Sequential ME Design.R:856-877).
+# det() of the Schur complement = det(R(D.old U D.new)) / det(R(D.old)), so R.old.Inv is not needed.
+if (ccgp.script == "BSQ") {
+  .ccgp.logdet <- function(D, p, theta1, theta2)
+    .Call("ccgp_R_mixed_logdet_designs", matrix(as.double(D), ncol = 1), nrow(D), ncol(D), 2L,
+          .ccgp.row(ncol(D), p, theta1, theta2))
+  Entropy <- function(D, p, theta1, theta2) -exp(.ccgp.logdet(as.matrix(D), p, theta1, theta2))
+  Augmented.Mixed.Entropy <- function(D.old, D.new, p, theta1, theta2, R.old.Inv = NULL)
+    -exp(.ccgp.logdet(rbind(as.matrix(D.old), as.matrix(D.new)), p, theta1, theta2) -
+         .ccgp.logdet(as.matrix(D.old), p, theta1, theta2))
+}

@@ -196,6 +196,19 @@ SEXP ccgp_R_sigma2_mle(SEXP R_inv, SEXP y, SEXP beta) {
   return Rf_ScalarReal(s);
 }
 
+/* log det R.mixed for B candidate designs (a list of n x d matrices flattened into an n*d x B matrix)
+ * -- Entropy / Augmented.Mixed.Entropy, Batch Sequential ME Design.R:856-877 */
+SEXP ccgp_R_mixed_logdet_designs(SEXP Xs, SEXP n, SEXP d, SEXP K, SEXP params) {
+  int B = Rf_ncols(Xs);
+  SEXP out = PROTECT(Rf_allocVector(REALSXP, B));
+  int rc = ccgp_mixed_logdet_designs(handle(), REAL(Xs), Rf_asInteger(n), Rf_asInteger(d), B,
+                                     Rf_asInteger(K), REAL(params), REAL(out), NULL);
+  if (rc < 0) { warn_rc(rc); fill_na(REAL(out), B); }
+  for (int i = 0; i < B; ++i) if (ISNAN(REAL(out)[i])) REAL(out)[i] = NA_REAL;
+  UNPROTECT(1);
+  return out;
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_corr_matrix", (DL_FUNC)&ccgp_R_corr_matrix, 2},
     {"ccgp_R_corr_cross", (DL_FUNC)&ccgp_R_corr_cross, 3},
@@ -209,6 +222,7 @@ static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_factors", (DL_FUNC)&ccgp_R_factors, 3},
     {"ccgp_R_beta_mle", (DL_FUNC)&ccgp_R_beta_mle, 2},
     {"ccgp_R_sigma2_mle", (DL_FUNC)&ccgp_R_sigma2_mle, 3},
+    {"ccgp_R_mixed_logdet_designs", (DL_FUNC)&ccgp_R_mixed_logdet_designs, 5},
     {NULL, NULL, 0}};
 
 void R_init_ccgpR(DllInfo* dll) {

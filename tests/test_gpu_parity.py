@@ -508,3 +508,27 @@ def test_gradient_matches_finite_differences(handle, case):
         assert ll[b] == pytest.approx(orc.loglik_general(X, y, w, Th, s2)[0], rel=1e-9)
         fd = orc.loglik_grad_fd(X, y, rows[b], K, d, s2)
         np.testing.assert_allclose(grad[b], fd, rtol=tol, atol=tol * np.abs(fd).max())
+
+
+# ------------------------------------------------------------------------------- 8(f)-4 entropy criteria
+def test_entropy_criteria_over_candidate_designs(handle):
+    """Batch Sequential ME Design.R:856-877: -det(R.mixed) for candidate designs, and the augmented
+    (Schur complement) criterion, against the oracle's literal restatement."""
+    from ccgp_amd.rsurface import CombinedGP
+    gp = CombinedGP("BSQ", handle=handle)
+    rng = np.random.default_rng(12)
+    p, t1, t2 = 0.7, 2.0, 16.0
+    designs = -1.0 + 2.0 * rng.random((37, 14, 2))          # 37 candidate 14-point designs in [-1,1]^2
+    got = gp.Entropy_batch(designs, p, t1, t2)
+    want = np.array([orc.entropy(D, p, t1, t2) for D in designs])
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    assert gp.Entropy(designs[3], p, t1, t2) == pytest.approx(want[3], rel=1e-9)
+    D_old, D_new = designs[0], -1.0 + 2.0 * rng.random((7, 2))
+    got_aug = gp.Augmented_Mixed_Entropy(D_old, D_new, p, t1, t2)
+    assert got_aug == pytest.approx(orc.augmented_mixed_entropy(D_old, D_new, p, t1, t2), rel=1e-8)
+    # 21-point designs (14 + 7, the script's second stage) and a 9-D case on the G = 16 template
+    d21 = -1.0 + 2.0 * rng.random((5, 21, 2))
+    np.testing.assert_allclose(gp.Entropy_batch(d21, p, t1, t2), [orc.entropy(D, p, t1, t2) for D in d21], rtol=1e-9)
+    d9 = rng.random((3, 90, 9))
+    np.testing.assert_allclose(gp.Entropy_batch(d9, 0.7, 0.3, 15.0), [orc.entropy(D, 0.7, 0.3, 15.0) for D in d9],
+                               rtol=1e-8)

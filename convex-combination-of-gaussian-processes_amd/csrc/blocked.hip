@@ -133,36 +133,68 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
     pQ += QI * stepQ;
   };
 
+  // Software pipeline.  Left to itself hipcc issues each k-step's fragment ds_reads and waits
+  // lgkmcnt(0) right before that step's MFMAs, exposing the LDS latency once per k-step.  Here the
+  // fragments of step kk+1 are loaded into a second register set BEFORE the MFMAs of step kk, and
+  // the stage barrier sits in front of the LAST k-step: the next stage's DMA and its first
+  // fragments are issued right after the barrier and land underneath that last k-step's MFMAs.
+  // (sched_barrier pins the order; the waits are the compiler's.)
+  static_assert(BKs == 16, "the pipeline below is written for four k-steps per stage");
+  double pfA[NY], qfA[NX], pfB[NY], qfB[NX];
+  const int sw = l4 & 1;   // k parity of this lane's fragment element (k = 4 kk + l4)
+#define CCGP_LOADF(PF, QF, STG, KK)                                                              \
+  do {                                                                                          \
+    const double* Ps_ = smem + (STG) * STAGE;                                                   \
+    const double* Qs_ = Ps_ + BKs * kTile;                                                      \
+    _Pragma("unroll") for (int y = 0; y < NY; ++y)                                              \
+        PF[y] = Ps_[((KK) * 4 + l4) * kTile + ((((row0 >> 4) + y) ^ sw) << 4) + l15];           \
+    _Pragma("unroll") for (int x = 0; x < NX; ++x)                                              \
+        QF[x] = Qs_[((KK) * 4 + l4) * CW + ((col_block<S, THIN, TRI>(wave, x) ^ sw) << 4) + l15]; \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+// MFMAs of one k-step in two parts, so that the NEXT step's fragment loads can be issued after
+// the first part: hipcc only emits lgkmcnt(0) waits (it does not count across the loop), and a
+// load issued right before a wait would expose its full latency; issued here it has the rest of
+// this step's MFMAs (12 of 16 at S = 1) to land before the next wait.
+#define CCGP_MFMAS(PF, QF, KT, X0, X1)                                                           \
+  do {                                                                                          \
+    if (active) {                                                                               \
+      _Pragma("unroll") for (int x = (X0); x < (X1); ++x) {                                     \
+        if (TRI && col_block<S, THIN, TRI>(wave, x) * 16 + 15 < (KT) * BKs) continue;           \
+        _Pragma("unroll") for (int y = 0; y < NY; ++y)                                          \
+            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(QF[x], PF[y], acc[x][y], 0, 0, 0); \
+      }                                                                                         \
+    }                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+  constexpr int XH = NX > 1 ? 1 : NX;   // MFMAs x < XH go before the prefetch, the rest after
+
   const int nk = Kdim / BKs;
   issue(0);
   __syncthreads();   // drains the DMA (vmcnt(0)) and publishes it
+  if (nk > 1) issue(1);
+  CCGP_LOADF(pfA, qfA, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) issue((kt + 1) & 1);
-    const double* Ps = smem + (kt & 1) * STAGE;
-    const double* Qs = Ps + BKs * kTile;
-    const int sw = l4 & 1;   // k parity of this lane's fragment element (k = 4 kk + l4)
-#pragma unroll
-    for (int kk = 0; kk < BKs / 4; ++kk) {
-      double pf[NY], qf[NX];
-#pragma unroll
-      for (int y = 0; y < NY; ++y)
-        pf[y] = Ps[(kk * 4 + l4) * kTile + ((((row0 >> 4) + y) ^ sw) << 4) + l15];
-#pragma unroll
-      for (int x = 0; x < NX; ++x)
-        qf[x] = Qs[(kk * 4 + l4) * CW + ((col_block<S, THIN, TRI>(wave, x) ^ sw) << 4) + l15];
-      if (active) {
-#pragma unroll
-        for (int x = 0; x < NX; ++x) {
-          if (TRI && col_block<S, THIN, TRI>(wave, x) < kt) continue;   // wave-uniform: zero block of W
-#pragma unroll
-          for (int y = 0; y < NY; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[x], pf[y], acc[x][y], 0, 0, 0);
-        }
-      }
+    const int stg = kt & 1;
+    CCGP_MFMAS(pfA, qfA, kt, 0, XH);
+    CCGP_LOADF(pfB, qfB, stg, 1);
+    CCGP_MFMAS(pfA, qfA, kt, XH, NX);
+    CCGP_MFMAS(pfB, qfB, kt, 0, XH);
+    CCGP_LOADF(pfA, qfA, stg, 2);
+    CCGP_MFMAS(pfB, qfB, kt, XH, NX);
+    CCGP_MFMAS(pfA, qfA, kt, 0, XH);
+    CCGP_LOADF(pfB, qfB, stg, 3);
+    CCGP_MFMAS(pfA, qfA, kt, XH, NX);
+    if (kt + 1 < nk) {
+      __syncthreads();                       // stage kt fully read by everyone, stage kt+1 landed
+      if (kt + 2 < nk) issue(stg);           // refill the buffer that was just released
     }
-    __syncthreads();
+    CCGP_MFMAS(pfB, qfB, kt, 0, XH);         // last k-step of stage kt, from registers
+    if (kt + 1 < nk) CCGP_LOADF(pfA, qfA, stg ^ 1, 0);   // first fragments of the next stage
+    CCGP_MFMAS(pfB, qfB, kt, XH, NX);
   }
-
+#undef CCGP_LOADF
+#undef CCGP_MFMAS
 }
 
 // C = C - acc (mode 0) or C = acc (mode 1) for one strip.

@@ -60,7 +60,7 @@ __device__ __forceinline__ void mat_sync() {
 }
 
 template <int G, int NB>
-__global__ __launch_bounds__(256) void small_reg_kernel(RegArgs a) {
+__global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs a) {
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
   constexpr int NP = G * NB;       // padded order
@@ -107,36 +107,65 @@ __global__ __launch_bounds__(256) void small_reg_kernel(RegArgs a) {
   double sw = 0.0;
   for (int c = 0; c < K; ++c) sw += w2[c];
   const double cs = a.sigma2 * sw;
-  const double post_scale = a.mode == 1 ? cs : 1.0;
+  // (p^2 R1 + (1-p)^2 R2) / (p^2 + (1-p)^2) (HX:412) as a multiplication by the reciprocal: one
+  // fp64 division costs ~30 instructions and this kernel is instruction-issue bound (<= 1 ulp apart)
+  const double post_scale = (a.mode == 1 ? cs : 1.0) / sw;
   const double post_shift = a.mode == 1 ? a.tau2 : 0.0;
 
   // ---- generate the lower triangle and the right-hand-side row into registers ------------------
+  // Per component q and column-block pair, the k-loop keeps the dot products
+  // s[a][j] = sum_k (x_rk theta_qk) x_ck of all the thread's entries in registers, so each
+  // (q, k) step costs the thread's row coordinates once per pair instead of three LDS reads
+  // and a loop iteration per ENTRY (this kernel is instruction-issue bound).
   double M[NB][NB];  // M[a][b], a >= b
   double E[NB];      // row ty of the right-hand-side block: ty = 0 -> y', ty = 1 -> 1'
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+    for (int aa = bb; aa < NB; ++aa) M[aa][bb] = 0.0;
+  for (int q = 0; q < K; ++q) {
+    const double wq = w2[q];
+#pragma unroll
+    for (int bb0 = 0; bb0 < NB; bb0 += 2) {
+      constexpr int kPair = 2;
+      double sdot[NB][kPair];
+#pragma unroll
+      for (int aa = 0; aa < NB; ++aa) sdot[aa][0] = sdot[aa][1] = 0.0;
+      const int c0 = min(tx + G * bb0, n - 1), c1 = min(tx + G * (bb0 + 1), n - 1);
+      for (int k = 0; k < d; ++k) {
+        const double tq = th[q * d + k];
+        const double xc0 = xs[k * n + c0], xc1 = xs[k * n + c1];
+#pragma unroll
+        for (int aa = bb0; aa < NB; ++aa) {
+          const double xr = xs[k * n + min(ty + G * aa, n - 1)] * tq;
+          sdot[aa][0] = fma(xr, xc0, sdot[aa][0]);
+          if (aa >= bb0 + 1 && bb0 + 1 < NB) sdot[aa][1] = fma(xr, xc1, sdot[aa][1]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kPair; ++j) {
+        const int bb = bb0 + j;
+        if (bb >= NB) continue;
+        const int c = tx + G * bb;
+#pragma unroll
+        for (int aa = bb; aa < NB; ++aa) {
+          const int r = ty + G * aa;
+          if (r < n && c < n && r >= c) {
+            const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
+            M[aa][bb] = fma(wq, exp(-dist), M[aa][bb]);
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int bb = 0; bb < NB; ++bb) {
     const int c = tx + G * bb;
 #pragma unroll
     for (int aa = bb; aa < NB; ++aa) {
       const int r = ty + G * aa;
-      double v;
-      if (r < n && c < n) {
-        if (r >= c) {
-          double acc = 0.0;
-          for (int q = 0; q < K; ++q) {
-            double s = 0.0;
-            for (int k = 0; k < d; ++k) s = fma(xs[k * n + r] * th[q * d + k], xs[k * n + c], s);
-            const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * s);
-            acc += w2[q] * exp(-dist);
-          }
-          v = post_scale * (acc / sw) + post_shift;
-        } else {
-          v = 0.0;  // strictly upper entry of a diagonal block: never read
-        }
-      } else {
-        v = r == c ? 1.0 : 0.0;  // identity on the padding
-      }
-      M[aa][bb] = v;
+      if (r < n && c < n) M[aa][bb] = r >= c ? fma(post_scale, M[aa][bb], post_shift) : 0.0;
+      else M[aa][bb] = r == c ? 1.0 : 0.0;   // identity on the padding
     }
     E[bb] = c < n ? (ty == 0 ? a.y[c] : (ty == 1 ? 1.0 : 0.0)) : 0.0;
   }
@@ -157,7 +186,10 @@ __global__ __launch_bounds__(256) void small_reg_kernel(RegArgs a) {
       mat_sync<G>();
       const double piv = cb[k];
       if (!(piv > 0.0)) { bad = k + 1; break; }   // uniform over the matrix's threads
-      const double rinv = 1.0 / piv;
+      // 1 / pivot by v_rcp_f64 + two Newton steps (full precision, ~6 instructions instead of ~30)
+      double rinv = __builtin_amdgcn_rcp(piv);
+      rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+      rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
       if (lt == 0) dvec[k] = piv;
       double lc[NB], lr[NB];
 #pragma unroll

@@ -879,8 +879,13 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   }
   {
     ScopedTimer t(h, CCGP_T_FUSED);
-    launch_small_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
-                         d_status);
+    static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
+    if (small_reg_supported(n, d, false, true) && !force_lds)
+      launch_small_reg_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
+                               d_status);
+    else
+      launch_small_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
+                           d_status);
   }
   CCGP_HIP(hipGetLastError());
   return CCGP_OK;

@@ -89,7 +89,10 @@ void launch_small_grad(hipStream_t s, const double* X, int n, int d, const doubl
                        int* status, double* gpart);
 
 // ---- small_reg.hip: register-resident evaluator for the plain likelihood (n <= 128) ---------
-bool small_reg_supported(int n, int d, bool per_design = false);
+bool small_reg_supported(int n, int d, bool per_design = false, bool predict = false);
+void launch_small_reg_predict(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
+                              int S, const double* Xtest, int m, double sigma2, double* mean, double* var,
+                              double* beta, int* status);
 void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int d, DrawView dv, int B,
                                      double* logdet, int* status);
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,

@@ -13,6 +13,10 @@
 //           matrices per workgroup -- n <= 64 (Heat-Exchanger grid, n = 64)
 //   G = 16: one workgroup per matrix, one barrier per column -- 64 < n <= 128
 // NB = ceil(n / G) is a template parameter so that every register index is static.
+// NE = number of G-row blocks of EXTRA rows: NE = 1 is the plain likelihood (rows y', 1');
+// NE = 4 serves prediction (predict.post, HX:655-673): rows 2.. of the extra block are the
+// cross-correlations r(x_t)' of a chunk of G NE - 2 test sites, eliminated like every other row,
+// so that afterwards they hold L'^-1 r(x_t) and mean / variance are D-weighted dot products.
 //
 // Bound: neither HBM nor MFMA -- n dependent elimination steps; algorithmic HBM traffic per
 // evaluation is the parameter row in (8 P bytes) and 20 bytes out.
@@ -37,14 +41,19 @@ struct RegArgs {
   int* status;
   // design-batched form (entropy criteria, BSQ:856-877): every evaluation has its OWN design
   // (X + b * x_stride) and all share one parameter row; only log det R_mixed is wanted
+  // prediction (NE > 1): test sites, S = leading dimension of the (draw x test site) tables
+  const double* Xt;
+  int m, S;
+  double* mean;
+  double* var;
   size_t x_stride;     // 0: one shared design
   int shared_params;   // 1: params is a single row
   double* logdet;      // optional output: sum_k log d_k
 };
 
-constexpr int kPerMat(int NP, int G) {  // doubles of LDS per matrix
-  return kMaxK * NP /*us*/ + kMaxK * kMaxD /*th*/ + kMaxK /*w2*/ + 2 * (NP + G) /*colbuf*/ + NP /*dvec*/ +
-         2 * NP /*zb*/ + 8;
+constexpr int kPerMat(int NP, int G, int NE = 1) {  // doubles of LDS per matrix
+  return kMaxK * NP /*us*/ + kMaxK * kMaxD /*th*/ + kMaxK /*w2*/ + 2 * (NP + G * NE) /*colbuf*/ + NP /*dvec*/ +
+         2 * NP /*zb*/ + 8 + (NE > 1 ? kMaxK * G * NE /*ut*/ + 3 * G * G * NE /*partial sums*/ : 0);
 }
 
 template <int G>
@@ -59,12 +68,14 @@ __device__ __forceinline__ void mat_sync() {
   }
 }
 
-template <int G, int NB>
-__global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs a) {
+template <int G, int NB, int NE>
+__global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_kernel(RegArgs a) {
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
   constexpr int NP = G * NB;       // padded order
-  constexpr int PM = kPerMat(NP, G);
+  constexpr int PM = kPerMat(NP, G, NE);
+  constexpr int XR = G * NE;       // extra rows (y', 1', then test sites)
+  constexpr int MT = XR - 2;       // test sites per chunk
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int n = a.n, d = a.d, K = a.K;
   const int tid = threadIdx.x, sub = tid / TPM, lt = tid % TPM;
@@ -78,16 +89,20 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
   double* us = mine;
   double* th = us + kMaxK * NP;
   double* w2 = th + kMaxK * kMaxD;
-  double* colbuf = w2 + kMaxK;                // [2][NP + G]
-  double* dvec = colbuf + 2 * (NP + G);
+  double* colbuf = w2 + kMaxK;                // [2][NP + XR]
+  double* dvec = colbuf + 2 * (NP + XR);
   double* zb = dvec + NP;                     // [2][NP]
+  double* ut = zb + 2 * NP + 8;               // [K][XR]   (NE > 1)
+  double* psum = ut + kMaxK * XR;             // [3][XR][G] (NE > 1)
+  const int t0 = blockIdx.y * MT;             // first test site of this chunk
+  double* xt = smem + (size_t)d * n + (size_t)MPW * PM;   // [d][XR], shared by the workgroup (NE > 1)
 
   const int pb = a.shared_params ? 0 : b;
   if (a.x_stride == 0) {
     for (int e = tid; e < n * d; e += 256) xs[e] = a.X[e];
   } else {
     // per-evaluation designs: each matrix keeps its own copy right behind the shared slot
-    xs = smem + (size_t)d * n + (size_t)MPW * PM + (size_t)sub * d * n;
+    xs = smem + (size_t)d * n + (size_t)MPW * PM + (size_t)sub * d * n;   // (never combined with NE > 1)
     for (int e = lt; e < n * d; e += TPM) xs[e] = a.X[(size_t)b * a.x_stride + e];
   }
   for (int e = lt; e < K * d; e += TPM) th[e] = a.params[pb + (size_t)(K + e) * a.ldp];
@@ -95,12 +110,26 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
     const double w = a.params[pb + (size_t)lt * a.ldp];
     w2[lt] = w * w;
   }
+  if constexpr (NE > 1) {
+    for (int e = tid; e < d * XR; e += 256) {
+      const int k = e / XR, r = e % XR, t = t0 + r - 2;
+      xt[e] = (r >= 2 && t < a.m) ? a.Xt[t + (size_t)k * a.m] : 0.0;
+    }
+  }
   __syncthreads();
   for (int e = lt; e < K * n; e += TPM) {
     const int c = e / n, i = e % n;
     double s = 0.0;
     for (int k = 0; k < d; ++k) { const double v = xs[k * n + i]; s += v * v * th[c * d + k]; }
     us[c * NP + i] = s;
+  }
+  if constexpr (NE > 1) {
+    for (int e = lt; e < K * XR; e += TPM) {
+      const int c = e / XR, r = e % XR;
+      double sq = 0.0;
+      for (int k = 0; k < d; ++k) { const double v = xt[k * XR + r]; sq += v * v * th[c * d + k]; }
+      ut[c * XR + r] = sq;
+    }
   }
   __syncthreads();
 
@@ -117,8 +146,8 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
   // s[a][j] = sum_k (x_rk theta_qk) x_ck of all the thread's entries in registers, so each
   // (q, k) step costs the thread's row coordinates once per pair instead of three LDS reads
   // and a loop iteration per ENTRY (this kernel is instruction-issue bound).
-  double M[NB][NB];  // M[a][b], a >= b
-  double E[NB];      // row ty of the right-hand-side block: ty = 0 -> y', ty = 1 -> 1'
+  double M[NB][NB];   // M[a][b], a >= b
+  double E[NE][NB];   // extra rows ty + G e: 0 -> y', 1 -> 1', 2.. -> r(x_t)' of this chunk's test sites
 #pragma unroll
   for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
@@ -167,7 +196,27 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
       if (r < n && c < n) M[aa][bb] = r >= c ? fma(post_scale, M[aa][bb], post_shift) : 0.0;
       else M[aa][bb] = r == c ? 1.0 : 0.0;   // identity on the padding
     }
-    E[bb] = c < n ? (ty == 0 ? a.y[c] : (ty == 1 ? 1.0 : 0.0)) : 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int ridx = ty + G * e;
+      double v = 0.0;
+      if (c < n) {
+        if (ridx == 0) v = a.y[c];
+        else if (ridx == 1) v = 1.0;
+        else if (NE > 1 && t0 + ridx - 2 < a.m) {
+          // Mixed.corr.vec (HX:425-431), corr.vec operation order (HX:373): (theta'x^2 - 2 X Theta x) + u_i
+          double acc = 0.0;
+          for (int q = 0; q < K; ++q) {
+            double sd = 0.0;
+            for (int k = 0; k < d; ++k) sd = fma(xs[k * n + c] * th[q * d + k], xt[k * XR + ridx], sd);
+            const double dist = (ut[q * XR + ridx] - 2.0 * sd) + us[q * NP + c];
+            acc = fma(w2[q], exp(-dist), acc);
+          }
+          v = acc / sw;
+        }
+      }
+      E[e][bb] = v;
+    }
   }
 
   // ---- L' D L'^T on registers; one column broadcast through LDS per step ------------------------
@@ -177,11 +226,12 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
     for (int kk = 0; kk < G; ++kk) {
       const int k = G * kb + kk;
       if (bad || k >= n) break;
-      double* cb = colbuf + cur * (NP + G);
+      double* cb = colbuf + cur * (NP + XR);
       if (tx == kk) {
 #pragma unroll
         for (int aa = kb; aa < NB; ++aa) cb[ty + G * aa] = M[aa][kb];
-        cb[NP + ty] = E[kb];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) cb[NP + ty + G * e] = E[e][kb];
       }
       mat_sync<G>();
       const double piv = cb[k];
@@ -198,12 +248,15 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
 #pragma unroll
       for (int aa = kb; aa < NB; ++aa) lr[aa] = cb[ty + G * aa];
       if (ty <= kk) lr[kb] = 0.0;   // rows <= k are finished
-      const double le = cb[NP + ty];
+      double le[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) le[e] = cb[NP + ty + G * e];
 #pragma unroll
       for (int bb = kb; bb < NB; ++bb) {
 #pragma unroll
         for (int aa = bb; aa < NB; ++aa) M[aa][bb] = fma(-lr[aa], lc[bb], M[aa][bb]);
-        E[bb] = fma(-le, lc[bb], E[bb]);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) E[e][bb] = fma(-le[e], lc[bb], E[e][bb]);
       }
       cur ^= 1;
     }
@@ -211,7 +264,7 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
   // z'_y[c] and z'_1[c] sit in threads ty = 0 / 1
   if (ty < 2) {
 #pragma unroll
-    for (int bb = 0; bb < NB; ++bb) zb[ty * NP + tx + G * bb] = E[bb];
+    for (int bb = 0; bb < NB; ++bb) zb[ty * NP + tx + G * bb] = E[0][bb];
   }
   mat_sync<G>();
 
@@ -249,45 +302,110 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 4) void small_reg_kernel(RegArgs 
       ll = -0.5 * (n * kLog2Pi + logdet + syy);
     }
     if (bad) { ll = kNaN; beta = kNaN; }
-    if (lt == 0 && valid) {
+    if (lt == 0) {
+      zb[2 * NP] = beta;      // for the prediction epilogue (slack words behind zb)
+      zb[2 * NP + 1] = s11;
+    }
+    if (lt == 0 && valid && blockIdx.y == 0) {
       if (a.loglik) a.loglik[b] = ll;
       if (a.beta) a.beta[b] = beta;
       if (a.status) a.status[b] = bad;
       if (a.logdet) a.logdet[b] = bad ? kNaN : logdet;
     }
   }
+  if constexpr (NE > 1) {
+    // mean = beta + (z_y - beta z_1).w ,  var = sigma2 (1 - w.w + (1 - z_1.w)^2 / (z_1.z_1)),
+    // dot products weighted by 1/d_k; w' = extra row of the test site (predict.post, HX:667-670)
+    mat_sync<G>();
+    const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+    double rd[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int c = tx + G * bb;
+      rd[bb] = (c < n && !bad) ? 1.0 / dvec[c] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      double ww = 0.0, z1w = 0.0, zyw = 0.0;
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) {
+        const int c = tx + G * bb;
+        if (c < n) {
+          const double w = E[e][bb], wr = w * rd[bb];
+          ww = fma(w, wr, ww);
+          z1w = fma(zb[NP + c], wr, z1w);
+          zyw = fma(zb[c], wr, zyw);
+        }
+      }
+      const int ridx = ty + G * e;
+      psum[(0 * XR + ridx) * G + tx] = ww;
+      psum[(1 * XR + ridx) * G + tx] = z1w;
+      psum[(2 * XR + ridx) * G + tx] = zyw;
+    }
+    mat_sync<G>();
+    const double beta = zb[2 * NP], s11 = zb[2 * NP + 1];
+    for (int ridx = 2 + lt; ridx < XR; ridx += TPM) {
+      const int t = t0 + ridx - 2;
+      if (t >= a.m || !valid) continue;
+      double ww = 0.0, z1w = 0.0, zyw = 0.0;
+#pragma unroll
+      for (int x = 0; x < G; ++x) {
+        ww += psum[(0 * XR + ridx) * G + x];
+        z1w += psum[(1 * XR + ridx) * G + x];
+        zyw += psum[(2 * XR + ridx) * G + x];
+      }
+      const double u = 1.0 - z1w;
+      double mean = beta + (zyw - beta * z1w);
+      double var = a.sigma2 * (1.0 - ww + u * u / s11);
+      if (bad) { mean = kNaN; var = kNaN; }
+      a.mean[b + (size_t)t * a.S] = mean;
+      a.var[b + (size_t)t * a.S] = var;
+    }
+  }
 }
 
-template <int G, int NB>
+template <int G, int NB, int NE>
+size_t reg_lds_bytes(const RegArgs& a) {
+  constexpr int MPW = 256 / (G * G);
+  return sizeof(double) * ((size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G, NE) +
+                           (a.x_stride ? (size_t)MPW * a.d * a.n : 0) + (NE > 1 ? (size_t)a.d * G * NE : 0));
+}
+
+template <int G, int NB, int NE = 1>
 void launch_one(hipStream_t s, const RegArgs& a) {
   constexpr int MPW = 256 / (G * G);
-  const size_t lds = sizeof(double) * ((size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G) +
-                                       (a.x_stride ? (size_t)MPW * a.d * a.n : 0));
+  const size_t lds = reg_lds_bytes<G, NB, NE>(a);
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
-    (void)hipFuncSetAttribute((const void*)small_reg_kernel<G, NB>,
+    (void)hipFuncSetAttribute((const void*)small_reg_kernel<G, NB, NE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
   }
+  const int chunks = NE > 1 ? (a.m + (G * NE - 2) - 1) / (G * NE - 2) : 1;
   const int kMaxGrid = 1 << 20;
   RegArgs c = a;
   for (int b0 = 0; b0 < a.B; b0 += kMaxGrid * MPW) {
     c.draw0 = a.draw0 + b0;
     c.B = a.B - b0 < kMaxGrid * MPW ? a.B - b0 : kMaxGrid * MPW;
-    hipLaunchKernelGGL((small_reg_kernel<G, NB>), dim3((c.B + MPW - 1) / MPW), dim3(256), lds, s, c);
+    hipLaunchKernelGGL((small_reg_kernel<G, NB, NE>), dim3((c.B + MPW - 1) / MPW, chunks), dim3(256), lds, s, c);
   }
 }
 
 }  // namespace
 
-bool small_reg_supported(int n, int d, bool per_design) {
+constexpr int kPredictNE = 4;   // extra row-blocks of the prediction instances: 30 (G = 8) / 62 (G = 16) sites per chunk
+
+bool small_reg_supported(int n, int d, bool per_design, bool predict) {
   if (n > 128) return false;
   const int G = n <= 64 ? 8 : 16;
   const int NB = (n + G - 1) / G;
   const int MPW = 256 / (G * G);
-  return sizeof(double) * ((size_t)d * n + (size_t)MPW * kPerMat(G * NB, G) +
-                           (per_design ? (size_t)MPW * d * n : 0)) <= (size_t)kLdsBytes - 64;
+  const int NE = predict ? kPredictNE : 1;
+  return sizeof(double) * ((size_t)d * n + (size_t)MPW * kPerMat(G * NB, G, NE) +
+                           (per_design ? (size_t)MPW * d * n : 0) + (predict ? (size_t)d * G * NE : 0)) <=
+         (size_t)kLdsBytes - 64;
 }
 
+template <int NE = 1>
 static void dispatch(hipStream_t s, const RegArgs& a);
 
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
@@ -313,25 +431,37 @@ void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int
   dispatch(s, a);
 }
 
+// predict.post for S draws x m test sites (mean / var are S x m column-major)
+void launch_small_reg_predict(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
+                              int S, const double* Xtest, int m, double sigma2, double* mean, double* var,
+                              double* beta, int* status) {
+  RegArgs a{};
+  a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
+  a.draw0 = 0; a.B = S; a.sigma2 = sigma2; a.mode = 0; a.tau2 = 0.0;
+  a.beta = beta; a.status = status; a.Xt = Xtest; a.m = m; a.S = S; a.mean = mean; a.var = var;
+  dispatch<kPredictNE>(s, a);
+}
+
+template <int NE>
 static void dispatch(hipStream_t s, const RegArgs& a) {
   const int n = a.n;
   if (n <= 64) {
     switch ((n + 7) / 8) {
-      case 1: launch_one<8, 1>(s, a); break;
-      case 2: launch_one<8, 2>(s, a); break;
-      case 3: launch_one<8, 3>(s, a); break;
-      case 4: launch_one<8, 4>(s, a); break;
-      case 5: launch_one<8, 5>(s, a); break;
-      case 6: launch_one<8, 6>(s, a); break;
-      case 7: launch_one<8, 7>(s, a); break;
-      default: launch_one<8, 8>(s, a); break;
+      case 1: launch_one<8, 1, NE>(s, a); break;
+      case 2: launch_one<8, 2, NE>(s, a); break;
+      case 3: launch_one<8, 3, NE>(s, a); break;
+      case 4: launch_one<8, 4, NE>(s, a); break;
+      case 5: launch_one<8, 5, NE>(s, a); break;
+      case 6: launch_one<8, 6, NE>(s, a); break;
+      case 7: launch_one<8, 7, NE>(s, a); break;
+      default: launch_one<8, 8, NE>(s, a); break;
     }
   } else {
     switch ((n + 15) / 16) {
-      case 5: launch_one<16, 5>(s, a); break;
-      case 6: launch_one<16, 6>(s, a); break;
-      case 7: launch_one<16, 7>(s, a); break;
-      default: launch_one<16, 8>(s, a); break;
+      case 5: launch_one<16, 5, NE>(s, a); break;
+      case 6: launch_one<16, 6, NE>(s, a); break;
+      case 7: launch_one<16, 7, NE>(s, a); break;
+      default: launch_one<16, 8, NE>(s, a); break;
     }
   }
 }

@@ -96,19 +96,35 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   const int gi = i0 + lane;
   const int rows_valid = a.lower_tiles ? a.npad : a.m;
   const int cols_valid = a.lower_tiles ? a.npad : a.n;
-  for (int jj = 0; jj < kCovCols / 4; ++jj) {
-    const int jl = wave * (kCovCols / 4) + jj;
-    const int gj = j0 + jl;
-    if (gj >= cols_valid) break;
-    double acc = 0.0;
-    for (int c = 0; c < K; ++c) {
-      double s = 0.0;
-      for (int k = 0; k < d; ++k) s = fma(xa[k * kCovRows + lane] * th[c * d + k], xb[k * kCovCols + jl], s);
-      double dist = (ua[c * kCovRows + lane] + ub[c * kCovCols + jl]) + (-2.0 * s);
-      acc += w2[c] * exp(-dist);
+  constexpr int JW = kCovCols / 4;   // 16 output columns per thread (one row, lane = row)
+  const int jl0 = wave * JW;
+  const double inv_sw = 1.0 / sw;    // (sum w_c^2 R_c) / sum w_c^2 as a multiplication (<= 1 ulp apart)
+  double accs[JW];
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) accs[jj] = 0.0;
+  // per component: the d-loop keeps the 16 dot products of this row in registers (one LDS read
+  // of the row coordinate and 16 broadcast reads per dimension instead of two reads per entry)
+  for (int c = 0; c < K; ++c) {
+    double sdot[JW];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) sdot[jj] = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double xr = xa[k * kCovRows + lane] * th[c * d + k];
+#pragma unroll
+      for (int jj = 0; jj < JW; ++jj) sdot[jj] = fma(xr, xb[k * kCovCols + jl0 + jj], sdot[jj]);
     }
-    double v = acc / sw;
-    v = post_scale * v + post_shift;
+    const double ur = ua[c * kCovRows + lane], wc = w2[c];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      const double dist = (ur + ub[c * kCovCols + jl0 + jj]) + (-2.0 * sdot[jj]);
+      accs[jj] = fma(wc, exp(-dist), accs[jj]);
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    const int gj = j0 + jl0 + jj;
+    if (gj >= cols_valid) break;
+    double v = fma(post_scale * inv_sw, accs[jj], post_shift);
     if (a.lower_tiles) {
       if (gi >= a.n || gj >= a.n) v = (gi == gj) ? 1.0 : 0.0;  // identity padding
     }

@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = "r01f/pmc_traffic.json"   # latest committed rocprofv3 --pmc passes of this bench command
 
 
 # ----------------------------------------------------------------------------- synthetic inputs
@@ -133,21 +134,22 @@ def cfg5_inputs(S=1000, seed=20140105):
     return sets, P
 
 
-def update_kernel_flops(n):
+def update_kernel_flops(n, diag_tiles=True):
     """Algorithmic flops of the trailing-update launches for ONE matrix: tile (i,j), i > j,
-    needs 2*128^3*j; a diagonal tile needs only its lower half."""
+    needs 2*128^3*j; a diagonal tile needs only its lower half.  diag_tiles=False: only the
+    rows below the diagonal (the diagonal tiles are then a separate launch on the second stream)."""
     nt = (n + 127) // 128
     t3 = 2.0 * 128 ** 3
-    return sum(j * t3 * ((nt - 1 - j) + 0.5) for j in range(1, nt))
+    return sum(j * t3 * ((nt - 1 - j) + (0.5 if diag_tiles else 0.0)) for j in range(1, nt))
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (counters cannot
     be read from inside the process; collected separately exactly as the MI355X guide prescribes)."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     try:
         with open(path) as fh:
-            return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/r01d_pmc_traffic.json"
+            return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/" + PMC_TRAFFIC_FILE
     except Exception:
         return None, None
 
@@ -292,7 +294,8 @@ def main():
         if args.workload == "cfg4":
             upd_ms, upd_launches = timing["update"]
             upd_ms = upd_ms or float("nan")
-            flops = update_kernel_flops(n) * B * args.steps          # this rank's launches
+            split = timing.get("update_diag", (0.0, 0))[1] > 0        # diagonal tiles launched separately
+            flops = update_kernel_flops(n, diag_tiles=not split) * B * args.steps   # this rank's launches
             ach = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
             traffic, traffic_src = pmc_traffic("chol_update") if (n == 4096 and B == 64) else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,

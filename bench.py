@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--n", type=int, default=4096, help="cfg4 matrix order (parity/debug runs only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path).  gloo: rehearsal of the N > 1 code path on "
+                         "a box with fewer GPUs than ranks (ranks share devices, results gathered through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -205,11 +208,17 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    host_gather = world > 1 and args.backend == "gloo"
 
     mode, tau2 = api.MEAN_PROFILE_BETA, 0.0
     if args.workload == "cfg4":
@@ -241,8 +250,9 @@ def main():
     sizes = shard.shard_sizes(total if args.workload == "cfg4" else total, world)
     if args.workload == "cfg2":
         sizes = [1000 * s for s in shard.shard_sizes(total // 1000, world)]
-    gather_buf = [torch.empty(max(sizes), **f64) for _ in range(world)] if world > 1 else None
-    send_buf = torch.zeros(max(sizes), **f64) if world > 1 else None
+    gdev = dict(dtype=torch.float64, device="cpu" if host_gather else dev)
+    gather_buf = [torch.empty(max(sizes), **gdev) for _ in range(world)] if world > 1 else None
+    send_buf = torch.zeros(max(sizes), **gdev) if world > 1 else None
 
     h = api.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -251,7 +261,7 @@ def main():
     def step():
         h.loglik_batch_dev(dX, n, d, dy, K, dP, B, sigma2, mode, tau2, d_ll, d_beta, d_st)
         if world > 1:
-            send_buf[:B] = d_ll
+            send_buf[:B] = d_ll                            # (gloo rehearsal: device -> host copy, synchronises)
             dist.all_gather(gather_buf, send_buf)          # the one collective of the path
 
     def fence():
@@ -272,9 +282,12 @@ def main():
     timing = h.get_timing()
     h.enable_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], **f64)
+        t = torch.tensor([elapsed], **gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank now holds every shard's log-likelihoods: check the gather against the local slice
+        full = torch.cat([g[:sz] for g, sz in zip(gather_buf, sizes)])
+        assert full.shape[0] == total and torch.equal(full[lo:hi].to(dev), d_ll), "all-gather mismatch"
     bad = int((d_st != 0).sum().item())
     finite = bool(torch.isfinite(d_ll).all().item())
 
@@ -287,7 +300,8 @@ def main():
             "scaling": "weak" if args.workload == "cfg4" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name, "n": n, "d": d, "K": K, "evals_total": total,
-                       "evals_per_gpu": B, "parallelism": "grid sharded over %d GPU(s), one all-gather" % world,
+                       "evals_per_gpu": B, "parallelism": "grid sharded over %d GPU(s), one all-gather%s" % (
+                           world, " (gloo rehearsal, ranks share devices)" if host_gather else ""),
                        "failed_evals": bad, "all_finite": finite},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in timing.items() if v[1]},
         }

@@ -1,8 +1,9 @@
 """Host-side counterpart of the reference's inference layer: `laplace`, `Metro`,
 `factors.frame`, `prediction`, `compare.GP`, `Combined.GP.fit` on top of the device evaluator.
 
-This layer is sequential and RNG-driven in the reference (HX:483-540, HX:686-725); it is not
-accelerated, only re-hosted so that the hot path has a complete caller.  Every likelihood /
+This layer is sequential and RNG-driven in the reference (HX:483-540, HX:686-725); it is re-hosted
+so that the hot path has a complete caller, and `Metro(..., speculate=m)` puts the sequential chain
+on the BATCHED device path without changing a bit of it (prefetching Metropolis).  Every likelihood /
 prediction it needs goes through libccgp (`rsurface.CombinedGP`).  RNG contract: numpy
 `Generator` (PCG64) seeded by the caller -- R's Mersenne-Twister stream cannot be reproduced
 without R, so agreement with the reference is statistical, never bitwise.
@@ -153,60 +154,119 @@ def geweke_z(x, frac1=0.1, frac2=0.5):
 
 # ----------------------------------------------------------------------------- Metro / factors.frame
 def Metro(gp, start, N, samp_size, batch_size, alpha, D_train, sigma2, y, theta1_pars=None,
-          theta2_pars=None, rng=None, max_proposals=None):
+          theta2_pars=None, rng=None, max_proposals=None, speculate=0, logpost_fn=None):
     """HX:483-540 (and its per-script copies).  Returns dict(sample[samp_size, p], beta[samp_size],
-    accepted, proposals, laplace)."""
+    accepted, proposals, laplace).
+
+    speculate = m > 1 evaluates the chain m proposals at a time ("prefetching" Metropolis): the
+    random numbers of the next m proposals are drawn first, the 2^m - 1 candidates the chain can
+    reach over those proposals (one per accept/reject history) go through the device evaluator as ONE
+    batch, and the accept/reject walk then only reads values.  Every candidate is evaluated by the
+    same kernel on its own workgroup, so the chain -- and the generator state it leaves behind -- is
+    bit-for-bit the sequential one; only the number of device round trips drops m-fold
+    (the sequential caller on the batched path).  `logpost_fn(rows) -> (val, beta)`
+    replaces the device evaluator (tests)."""
     from scipy.stats import norm
 
     rng = np.random.default_rng(rng)
     pars = None
-    if gp.script in ("HX", "ADV"):
-        pars = (*np.ravel(theta1_pars)[:2], *np.ravel(theta2_pars)[:2])
+    if logpost_fn is None:
+        if gp.script in ("HX", "ADV"):
+            pars = (*np.ravel(theta1_pars)[:2], *np.ravel(theta2_pars)[:2])
+
+        def logpost_fn(rows):
+            return logpost_batch(gp, D_train, rows, y, sigma2, pars)
 
     def val_batch(rows):
-        return logpost_batch(gp, D_train, rows, y, sigma2, pars)[0]
+        return logpost_fn(rows)[0]
 
     est = laplace(val_batch, start)
     mu, V = est["mode"], est["var"]
     cov = math.sqrt(2.0) * V
     p = mu.size
+    zero = np.zeros(p)
     samp = np.zeros((N, p))
     betas = np.zeros(N)
-    theta_old = mu.copy()
-    l_old, _ = logpost_batch(gp, D_train, theta_old[None], y, sigma2, pars)
-    l_old = float(l_old[0])
-    k, pv, proposals = 0, 0.0, 0
+    st = dict(theta=mu.copy(), l=float(logpost_fn(mu[None])[0][0]), k=0, pv=0.0, proposals=0, batches=0)
     max_proposals = max_proposals or 200 * N
-    while k < N and pv < alpha and proposals < max_proposals:
+
+    def draw_pair():
+        # same stream as `u <- runif(1); rmnorm(1, theta.old, cov)` (HX:507-511): the proposal is
+        # theta.old + e with e ~ N(0, cov), and adding the mean afterwards is what numpy does too
         u = rng.random()
-        cand = rng.multivariate_normal(theta_old, cov)
-        proposals += 1
-        l_cand, b_cand = logpost_batch(gp, D_train, cand[None], y, sigma2, pars)
-        l_cand = float(l_cand[0])
-        if math.isfinite(l_cand) and (l_cand - l_old) > math.log(u):
-            samp[k] = cand
-            betas[k] = b_cand[0]
-            theta_old, l_old = cand, l_cand
-            k += 1
-            if k >= samp_size and k % batch_size == 0:
-                try:   # first parameter's chain over the last samp_size + 1 accepted draws (HX:530)
-                    z = geweke_z(samp[max(k - samp_size - 1, 0):k, 0])
-                    pv = float(2.0 * (1.0 - norm.cdf(abs(z))))
-                except Exception:
-                    pv = 0.0
+        return u, rng.multivariate_normal(zero, cov)
+
+    def running():
+        return st["k"] < N and st["pv"] < alpha and st["proposals"] < max_proposals
+
+    def consume(u, cand, l_cand, b_cand):
+        """One proposal of HX:505-535 given its value.  Returns True when it was accepted."""
+        st["proposals"] += 1
+        if not (math.isfinite(l_cand) and (l_cand - st["l"]) > math.log(u)):
+            return False
+        k = st["k"]
+        samp[k] = cand
+        betas[k] = b_cand
+        st["theta"], st["l"], st["k"] = cand, l_cand, k + 1
+        k += 1
+        if k >= samp_size and k % batch_size == 0:
+            try:   # first parameter's chain over the last samp_size + 1 accepted draws (HX:530)
+                z = geweke_z(samp[max(k - samp_size - 1, 0):k, 0])
+                st["pv"] = float(2.0 * (1.0 - norm.cdf(abs(z))))
+            except Exception:
+                st["pv"] = 0.0
+        return True
+
+    m = int(speculate)
+    if m <= 1:
+        while running():
+            u, e = draw_pair()
+            cand = st["theta"] + e
+            l_cand, b_cand = logpost_fn(cand[None])
+            st["batches"] += 1
+            consume(u, cand, float(l_cand[0]), float(b_cand[0]))
+    else:
+        state0 = rng.bit_generator.state
+        pending = []                      # pre-drawn (u, e) pairs not yet consumed
+        while running():
+            while len(pending) < m:
+                pending.append(draw_pair())
+            # level t holds the 2^t candidates reachable after t proposals; history bits: 1 = accepted
+            states, levels = [st["theta"]], []
+            for t in range(m):
+                e = pending[t][1]
+                cands = [s + e for s in states]
+                levels.append(cands)
+                states = [x for s, c in zip(states, cands) for x in (s, c)]
+            l_all, b_all = logpost_fn(np.asarray([c for lv in levels for c in lv]))
+            st["batches"] += 1
+            idx, off, used = 0, 0, 0
+            for t in range(m):
+                if not running():
+                    break
+                acc = consume(pending[t][0], levels[t][idx], float(l_all[off + idx]), float(b_all[off + idx]))
+                used += 1
+                off += 1 << t
+                idx = 2 * idx + (1 if acc else 0)
+            pending = pending[used:]
+        # leave the generator where the sequential chain leaves it: exactly `proposals` pairs drawn
+        rng.bit_generator.state = state0
+        for _ in range(st["proposals"]):
+            draw_pair()
+    k = st["k"]
     if k < samp_size:
-        raise RuntimeError("Metro: only %d accepted draws after %d proposals" % (k, proposals))
+        raise RuntimeError("Metro: only %d accepted draws after %d proposals" % (k, st["proposals"]))
     return dict(sample=samp[k - samp_size:k].copy(), beta=betas[k - samp_size:k].copy(), accepted=k,
-                proposals=proposals, laplace=est, geweke_p=pv)
+                proposals=st["proposals"], laplace=est, geweke_p=st["pv"], device_batches=st["batches"])
 
 
 def factors_frame(gp, start, N, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train,
-                  net_samp_size, theta1_pars=None, theta2_pars=None, rng=None):
+                  net_samp_size, theta1_pars=None, theta2_pars=None, rng=None, speculate=0):
     """HX:625-644 without materialising R.Inv per draw: returns the retained posterior draws
     (p, theta1, theta2[, lambda]) and their beta; the device recomputes the factor when predicting
     (rsurface.CombinedGP.factors_frame_from_draws builds the reference's wide frame on request)."""
     s = Metro(gp, start, N, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train, theta1_pars,
-              theta2_pars, rng)
+              theta2_pars, rng, speculate=speculate)
     keep = slice(samp_size - net_samp_size, samp_size)
     return dict(draws=transformed_to_draws(s["sample"][keep]), beta=s["beta"][keep], chain=s)
 
@@ -276,7 +336,7 @@ def ordinary_kriging_sigma2(handle, D_train, y_train, starts=3, rng=0):
 
 def Combined_GP_fit(gp, D_train, y_train, D_new, start, N_max, samp_size, alpha_geweke, batch_size,
                     alpha=0.05, net_samp_size=None, y_new=None, sigma2=None, theta1_pars=None,
-                    theta2_pars=None, rng=None):
+                    theta2_pars=None, rng=None, speculate=0):
     """ISO:736-783 / ANI:730-777 / D1:989-1016 minus the plots: sigma2 (ordinary kriging) ->
     posterior draws (laplace + Metro) -> predictions with intervals at D.new."""
     rng = np.random.default_rng(rng)
@@ -284,7 +344,7 @@ def Combined_GP_fit(gp, D_train, y_train, D_new, start, N_max, samp_size, alpha_
         sigma2, _, _ = ordinary_kriging_sigma2(gp.h, D_train, y_train)
     net = net_samp_size or samp_size
     ff = factors_frame(gp, start, N_max, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train, net,
-                       theta1_pars, theta2_pars, rng)
+                       theta1_pars, theta2_pars, rng, speculate=speculate)
     y_new = np.full(np.asarray(D_new).shape[0], np.nan) if y_new is None else y_new
     table = compare_GP(gp, D_new, alpha, y_new, ff["draws"], D_train, sigma2, y_train, rng)
     table.update(sigma2=sigma2, draws=ff["draws"], beta=ff["beta"], chain=ff["chain"])

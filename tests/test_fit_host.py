@@ -48,3 +48,35 @@ def test_spectrum0_and_geweke_on_ar1():
     assert abs(np.mean(zs)) < 0.8 and 0.5 < np.std(zs) < 1.6       # ~ N(0, 1) for a stationary chain
     drift = x[:2000] + np.linspace(0, 6, 2000)
     assert abs(fit.geweke_z(drift)) > 3                              # a drifting chain is flagged
+
+
+@pytest.mark.parametrize("m", [2, 5])
+def test_speculative_metro_is_the_sequential_chain_bit_for_bit(m):
+    """Metro(speculate=m) evaluates 2^m - 1 candidates per device round trip; the chain, the betas,
+    the counters and the generator state it leaves behind must equal the sequential run exactly."""
+    mu = np.array([0.4, -0.7, 1.1])
+    A = np.array([[0.30, 0.05, 0.00], [0.05, 0.20, -0.04], [0.00, -0.04, 0.10]])
+    P = np.linalg.inv(A)
+    calls = []
+
+    def logpost_fn(rows):
+        rows = np.atleast_2d(rows)
+        calls.append(rows.shape[0])
+        dlt = rows - mu
+        val = -0.5 * np.einsum("ij,jk,ik->i", dlt, P, dlt)
+        val = np.where(rows[:, 2] > 1.9, np.nan, val)        # an NA region (HX:454-455): never accepted
+        return val, rows.sum(axis=1)
+
+    args = (None, np.zeros(3), 400, 60, 10, 0.5, None, 1.0, None)
+    r_seq, r_spec = np.random.default_rng(11), np.random.default_rng(11)
+    seq = fit.Metro(*args, rng=r_seq, logpost_fn=logpost_fn)
+    n_seq_calls = len(calls)
+    del calls[:]
+    spec = fit.Metro(*args, rng=r_spec, logpost_fn=logpost_fn, speculate=m)
+    np.testing.assert_array_equal(seq["sample"], spec["sample"])
+    np.testing.assert_array_equal(seq["beta"], spec["beta"])
+    assert (seq["accepted"], seq["proposals"], seq["geweke_p"]) == (spec["accepted"], spec["proposals"], spec["geweke_p"])
+    assert r_seq.random() == r_spec.random()                  # same generator state afterwards
+    assert calls.count(2 ** m - 1) == spec["device_batches"]   # every chain round trip carries the whole tree
+    assert spec["device_batches"] <= -(-seq["proposals"] // m) + 1 < seq["device_batches"]
+    assert n_seq_calls > len(calls)

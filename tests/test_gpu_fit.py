@@ -43,3 +43,28 @@ def test_heat_exchanger_fit(handle):
     print("Qian: RMSPE %.3f, coverage %.2f" % (s["rmspe"], s["coverage"]))
     assert s["rmspe"] < 0.5 * np.std(yt)          # far better than predicting the mean
     assert s["coverage"] >= 0.7                   # 14 test points only
+
+
+def test_speculative_metro_on_the_device_is_the_sequential_chain(handle):
+    """Metro on the BATCHED device path.  speculate=5 sends 31 candidates per round
+    trip; every candidate is evaluated by its own wave of the same kernel, so the chain is the
+    sequential one bit for bit -- with a fifth of the device round trips."""
+    import time
+    from ccgp_amd import fit
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, _, _ = load_qian()
+    gp = CombinedGP("HX", handle=handle)
+    s2 = float(np.var(y, ddof=1))
+    kw = dict(theta1_pars=(7, 3), theta2_pars=(3, 28))
+    args = (gp, [1.0, 2.7, 0.0], 600, 200, 20, 0.5, D, s2, y)
+    t0 = time.perf_counter()
+    seq = fit.Metro(*args, rng=np.random.default_rng(3), **kw)
+    t1 = time.perf_counter()
+    spec = fit.Metro(*args, rng=np.random.default_rng(3), speculate=5, **kw)
+    t2 = time.perf_counter()
+    np.testing.assert_array_equal(seq["sample"], spec["sample"])
+    np.testing.assert_array_equal(seq["beta"], spec["beta"])
+    assert (seq["accepted"], seq["proposals"]) == (spec["accepted"], spec["proposals"])
+    assert spec["device_batches"] * 4 < seq["device_batches"]
+    print("Metro on Qian: %d proposals, sequential %d round trips %.2f s, speculate=5 %d round trips %.2f s"
+          % (seq["proposals"], seq["device_batches"], t1 - t0, spec["device_batches"], t2 - t1))

@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void rinv_tile_kernel(RinvArgs g) {
             double sdot = 0.0;
             for (int k = 0; k < d; ++k) sdot = fma(xa[k * kTile + lr] * th[q * d + k], xb[k * kTile + lc], sdot);
             const double dist = (ua[q * kTile + lr] + ub[q * kTile + lc]) + (-2.0 * sdot);
-            const double v = acc[x][y][r] * exp(-dist);
+            const double v = acc[x][y][r] * exp_cov(-dist);
             T[x][y][r] = v;
             gsum += v;
           }

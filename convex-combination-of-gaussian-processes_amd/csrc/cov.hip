@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
       const double dist = (ur + ub[c * kCovCols + jl0 + jj]) + (-2.0 * sdot[jj]);
-      accs[jj] = fma(wc, exp(-dist), accs[jj]);
+      accs[jj] = fma(wc, exp_cov(-dist), accs[jj]);
     }
   }
 #pragma unroll

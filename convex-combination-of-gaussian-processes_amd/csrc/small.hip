@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           double s = 0.0;
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + i] * th[c * d + k], xs[k * n + j], s);
           double dist = (us[c * n + i] + us[c * n + j]) + (-2.0 * s);
-          acc += w2[c] * exp(-dist);
+          acc += w2[c] * exp_cov(-dist);
         }
         v = post_scale * (acc / sw) + post_shift;
       } else if (i == n) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + j] * th[c * d + k], xt[k * a.mtile + t], s);
           // corr.vec order: (theta'x^2 - 2 X Theta x) + u_i   (HX:373)
           double dist = (ut[c * a.mtile + t] - 2.0 * s) + us[c * n + j];
-          acc += w2[c] * exp(-dist);
+          acc += w2[c] * exp_cov(-dist);
         }
         v = acc / sw;
       } else {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           double s = 0.0;
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + i] * th[c * d + k], xs[k * n + jt], s);
           double dist = (us[c * n + i] + us[c * n + jt]) + (-2.0 * s);
-          double rc = exp(-dist);
+          double rc = exp_cov(-dist);
           if (kk >= 0) { double df = xs[kk * n + i] - xs[kk * n + jt]; rc *= df * df; }
           acc = fma(Mit, rc, acc);
         }

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
           const int r = ty + G * aa;
           if (r < n && c < n && r >= c) {
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
-            M[aa][bb] = fma(wq, exp(-dist), M[aa][bb]);
+            M[aa][bb] = fma(wq, exp_cov(-dist), M[aa][bb]);
           }
         }
       }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
             double sd = 0.0;
             for (int k = 0; k < d; ++k) sd = fma(xs[k * n + c] * th[q * d + k], xt[k * XR + ridx], sd);
             const double dist = (ut[q * XR + ridx] - 2.0 * sd) + us[q * NP + c];
-            acc = fma(w2[q], exp(-dist), acc);
+            acc = fma(w2[q], exp_cov(-dist), acc);
           }
           v = acc / sw;
         }

@@ -17,6 +17,7 @@ MEAN_PROFILE_BETA = 0
 MEAN_ZERO_PLUS_TAU2 = 1
 PRIOR_INVGAMMA, PRIOR_GV, PRIOR_ISO, PRIOR_ANI = 0, 1, 2, 3
 T_COV, T_UPDATE, T_DIAG, T_TRSM, T_SOLVE, T_FUSED = range(6)
+KERNEL_GAUSS, KERNEL_MATERN = 0, 1
 TIMING_NAMES = ("cov", "update", "diag", "trsm", "solve", "fused")
 
 _dp = POINTER(c_double)
@@ -29,6 +30,7 @@ SIGNATURES = {
     "ccgp_last_error": (c_char_p, [c_void_p]),
     "ccgp_version": (c_char_p, []),
     "ccgp_set_stream": (c_int, [c_void_p, c_void_p]),
+    "ccgp_set_kernel": (c_int, [c_void_p, c_int, c_double]),
     "ccgp_set_workspace_limit": (c_int, [c_void_p, c_size_t]),
     "ccgp_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "ccgp_synchronize": (c_int, [c_void_p]),
@@ -152,6 +154,11 @@ class Handle:
     # -- plumbing ----------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr):
         self._chk(lib().ccgp_set_stream(self._h, c_void_p(hip_stream_ptr or 0)))
+
+    def set_kernel(self, family=0, nu=0.0):
+        """Correlation family for the calls that follow: KERNEL_GAUSS (default) or KERNEL_MATERN with
+        smoothness nu (the 1-D scripts, D1:348-351; d must then be 1)."""
+        self._chk(lib().ccgp_set_kernel(self._h, int(family), float(nu)))
 
     def set_workspace_limit(self, nbytes):
         self._chk(lib().ccgp_set_workspace_limit(self._h, int(nbytes)))

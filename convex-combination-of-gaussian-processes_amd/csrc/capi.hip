@@ -99,9 +99,15 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
     return fail(h, CCGP_EINVAL, "ccgp_loglik_batch: unknown mean_mode");
   if (B == 0) return CCGP_OK;
   DrawView dv{dparams, B, K, d};
+  dv.fam = h->fam;
+  if (dv.fam.id != 0 && d != 1)
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
   static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
-  const bool reg_ok = small_reg_supported(n, d) && !force_lds;
-  const bool lds_ok = n <= kSmallMaxN && small_lds_bytes(n, d, 0) <= (size_t)kLdsBytes - 64;
+  // the fused evaluators generate Gaussian correlations in registers; any other family goes through
+  // the materialised-matrix (blocked) path, where only cov_kernel knows about families
+  const bool gauss = dv.fam.id == 0;
+  const bool reg_ok = gauss && small_reg_supported(n, d) && !force_lds;
+  const bool lds_ok = gauss && n <= kSmallMaxN && small_lds_bytes(n, d, 0) <= (size_t)kLdsBytes - 64;
   if (reg_ok || lds_ok) {   // otherwise (n > 128, or d too large for LDS) the blocked path takes it
     ScopedTimer t(h, CCGP_T_FUSED);
     if (reg_ok)
@@ -276,6 +282,20 @@ int ccgp_set_stream(ccgp_handle* h, void* hip_stream) {
   return CCGP_OK;
 }
 
+int ccgp_set_kernel(ccgp_handle* h, int family, double nu) {
+  if (!h) return CCGP_EINVAL;
+  if (family == CCGP_KERNEL_GAUSS) {
+    h->fam = ccgp::KernelFamily{};
+    return CCGP_OK;
+  }
+  if (family != CCGP_KERNEL_MATERN || !(nu > 1.0) || !(nu <= 64.0))
+    return fail(h, CCGP_EINVAL, "ccgp_set_kernel: family must be CCGP_KERNEL_GAUSS or CCGP_KERNEL_MATERN with 1 < nu <= 64");
+  h->fam.id = CCGP_KERNEL_MATERN;
+  h->fam.nu = nu;
+  h->fam.norm = 1.0 / (std::tgamma(nu) * std::pow(2.0, nu - 1.0));
+  return CCGP_OK;
+}
+
 int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes) {
   if (!h || bytes < (size_t(1) << 20)) return CCGP_EINVAL;
   h->ws_limit = bytes;
@@ -291,7 +311,7 @@ int ccgp_synchronize(ccgp_handle* h) {
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m) {
   if (!h || bad_shape(n, d, K) || B < 1 || m < 0) return fail(h, CCGP_EINVAL, "ccgp_reserve: bad argument");
   CCGP_HIP(hipSetDevice(h->device));
-  if (n > kSmallMaxN) {
+  if (n > kSmallMaxN || h->fam.id != 0) {
     const int npad = round_up(n, kTile);
     const int ne = (m + kTile - 1) / kTile;
     int rc = ensure_ws(h, blocked_ws_bytes(npad, blocked_chunk(h, npad, B, ne), ne));
@@ -349,6 +369,9 @@ static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* 
     CCGP_HIP(hipMemcpyAsync(dXn, Xnew, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice, h->stream));
   CCGP_HIP(hipMemcpyAsync(dp, params_row, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
   DrawView dv{dp, 1, K, d};
+  dv.fam = h->fam;
+  if (dv.fam.id != 0 && d != 1)
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
   {
     ScopedTimer t(h, CCGP_T_COV);
     launch_cov_dense(h->stream, gram ? dX : dXn, m, dX, n, d, dv, 0, dout, m);
@@ -523,6 +546,8 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || B < 1 || !X || !y || !params || !out_grad)
     return fail(h, CCGP_EINVAL, "ccgp_loglik_grad_batch: bad argument");
+  if (h->fam.id != 0)
+    return fail(h, CCGP_EUNSUPPORTED, "ccgp_loglik_grad_batch: analytic gradient is implemented for the Gaussian family only");
   CCGP_HIP(hipSetDevice(h->device));
   const int P = K + K * d;
   if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
@@ -554,6 +579,9 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
     CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
     CCGP_HIP(hipMemsetAsync(dst, 0, sizeof(int) * (size_t)B, h->stream));
     DrawView dv{dp, B, K, d};
+    dv.fam = h->fam;
+    if (dv.fam.id != 0 && d != 1)
+      return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
     Carver tail(static_cast<char*>(h->ws) + Carver::al(blocked_ws_bytes(npad, nbc, ne)));
     BlockedJob job{};
     job.kind = kJobGrad; job.grad = dg; job.Btot = B;
@@ -594,6 +622,9 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
   DrawView dv{dp, B, K, d};
+  dv.fam = h->fam;
+  if (dv.fam.id != 0 && d != 1)
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     launch_small_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst, dgp);
@@ -652,7 +683,7 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   int rc = ccgp_loglik_batch(h, X, n, d, y, K, row.data(), 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0,
                              &ll, &beta, &st);
   if (rc < 0) return rc;
-  if (out_Rinv && (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)) {
+  if (out_Rinv && (h->fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)) {
     // blocked path: one more sweep with the identity as extra rows, then R^-1 = Z Z' tile by tile
     const int npad = round_up(n, kTile), nt = npad / kTile;
     size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
@@ -675,6 +706,9 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     CCGP_HIP(hipMemcpyAsync(dp, row.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     CCGP_HIP(hipMemsetAsync(dst, 0, sizeof(int), h->stream));
     DrawView dv{dp, 1, K, d};
+    dv.fam = h->fam;
+    if (dv.fam.id != 0 && d != 1)
+      return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
     BlockedJob job{};
     job.kind = kJobInverse; job.Rinv = dR;
     BlockedWs w = blocked_carve(h->ws, npad, 1, nt);
@@ -695,6 +729,9 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
     CCGP_HIP(hipMemcpyAsync(dp, row.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     DrawView dv{dp, 1, K, d};
+    dv.fam = h->fam;
+    if (dv.fam.id != 0 && d != 1)
+      return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
     {
       ScopedTimer t(h, CCGP_T_FUSED);
       launch_small_inverse(h->stream, dX, n, d, dv, 0, dR, dst);
@@ -716,6 +753,8 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || B < 1 || !Xs || !params || !out_logdet)
     return fail(h, CCGP_EINVAL, "ccgp_mixed_logdet_designs: bad argument");
+  if (h->fam.id != 0)
+    return fail(h, CCGP_EUNSUPPORTED, "ccgp_mixed_logdet_designs: Gaussian family only (BSQ:856-877)");
   if (!small_reg_supported(n, d, true))
     return fail(h, CCGP_EUNSUPPORTED, "ccgp_mixed_logdet_designs: designs of more than 128 points (or too wide for LDS) not implemented");
   CCGP_HIP(hipSetDevice(h->device));
@@ -732,6 +771,9 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
   CCGP_HIP(hipMemcpyAsync(dXs, Xs, sizeof(double) * (size_t)B * n * d, hipMemcpyHostToDevice, h->stream));
   CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
   DrawView dv{dp, 1, K, d};
+  dv.fam = h->fam;
+  if (dv.fam.id != 0 && d != 1)
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     launch_small_reg_logdet_designs(h->stream, dXs, n, d, dv, B, dld, dst);
@@ -853,7 +895,10 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
     return fail(h, CCGP_EINVAL, "ccgp_predict_batch: bad argument");
   CCGP_HIP(hipSetDevice(h->device));
   DrawView dv{dparams, S, K, d};
-  if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
+  dv.fam = h->fam;
+  if (dv.fam.id != 0 && d != 1)
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+  if (dv.fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
     // blocked path: the m cross-correlation rows ride along as extra tile rows of the sweep
     const int npad = round_up(n, kTile), ne = (m + kTile - 1) / kTile;
     const int nbc = blocked_chunk(h, npad, S, ne);

@@ -23,6 +23,7 @@ struct CovArgs {
   const double* Bm;  // n x d column-major (columns of the output)
   int m, n, d;
   const double* params;
+  KernelFamily fam;
   int ldp, K;
   int draw0;
   double* out;
@@ -35,6 +36,8 @@ struct CovArgs {
 };
 
 // LDS: xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
+// FAM = 0: Gaussian (the hot instantiation: nothing of the Matern code in it); FAM = 1: Matern (D1:348-351)
+template <int FAM>
 __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int d = a.d, K = a.K;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int i0 = tr * kCovRows, j0 = tc * kCovCols;
 
-  for (int e = tid; e < K * d; e += 256) th[e] = a.params[b + (size_t)(K + e) * a.ldp];
+  for (int e = tid; e < K * d; e += 256) th[e] = FAM == 0 ? a.params[b + (size_t)(K + e) * a.ldp] : theta_to_rate(a.fam, a.params[b + (size_t)(K + e) * a.ldp]);
   if (tid < K) {
     double w = a.params[b + (size_t)tid * a.ldp];
     w2[tid] = w * w;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
       const double dist = (ur + ub[c * kCovCols + jl0 + jj]) + (-2.0 * sdot[jj]);
-      accs[jj] = fma(wc, exp_cov(-dist), accs[jj]);
+      accs[jj] = fma(wc, (FAM == 0 ? exp_cov(-dist) : matern_corr(a.fam, dist)), accs[jj]);
     }
   }
 #pragma unroll
@@ -142,10 +145,11 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
                       DrawView dv, int draw, double* out, int ldo) {
   CovArgs a{};
   a.A = A; a.Bm = Bm; a.m = m; a.n = n; a.d = d;
-  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = draw;
+  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = draw;
   a.out = out; a.batch_stride = 0; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
   dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, 1);
-  hipLaunchKernelGGL(cov_kernel, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
 }
 
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
@@ -153,12 +157,13 @@ void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv,
                       double tau2, int ld) {
   CovArgs a{};
   a.A = X; a.Bm = X; a.m = n; a.n = n; a.d = d;
-  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = b0;
+  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
   a.out = Abase; a.batch_stride = batch_stride; a.ldo = ld; a.mode = mean_mode;
   a.sigma2 = sigma2; a.tau2 = tau2; a.lower_tiles = 1; a.npad = npad;
   int nt64 = npad / 64;
   dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
-  hipLaunchKernelGGL(cov_kernel, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
 }
 
 // Batched cross-correlation rows for the blocked prediction path: for draw b0+z the m x n block
@@ -167,10 +172,11 @@ void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const d
                               DrawView dv, int b0, int nb, double* Abase, size_t batch_stride, int ldo) {
   CovArgs a{};
   a.A = Xtest; a.Bm = X; a.m = m; a.n = n; a.d = d;
-  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.draw0 = b0;
+  a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
   a.out = Abase; a.batch_stride = batch_stride; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
   dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, nb);
-  hipLaunchKernelGGL(cov_kernel, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
 }
 
 }  // namespace ccgp

@@ -49,7 +49,7 @@ def log_prior(theta_t, script, prior_pars=None):
         return -(a1 + 1.0) * psi1 - b1 / th1 - (a2 + 1.0) * psi2 - b2 / th2
     if script == "GV":
         return -4.0 * psi1 - 1.0 / th1 - 6.0 * psi2 - 75.0 / th2
-    if script in ("ISO", "BSQ"):
+    if script in ("ISO", "BSQ", "D1"):   # D1:636 = ISO:453
         return -4.0 * psi1 - 2.0 / th1 - 6.0 * psi2 - 16.0 / th2
     if script == "ANI":
         zeta = t[:, 3]

@@ -39,6 +39,27 @@ def pack_aniso(p, theta1, theta2, lam):
     return np.array([p, 1.0 - p, theta1, theta2, (1.0 + lam) * theta1, (1.0 + lam) * theta2], dtype=np.float64)
 
 
+class _FamilyHandle:
+    """api.Handle proxy that (re)selects the correlation family before every call, so that objects
+    mirroring different scripts can share one device handle."""
+
+    def __init__(self, handle, family, nu):
+        self._handle, self._family, self._nu = handle, family, nu
+
+    def __getattr__(self, name):
+        attr = getattr(self._handle, name)
+        if not callable(attr) or name in ("close", "set_kernel"):
+            return attr
+
+        def call(*args, **kwargs):
+            self._handle.set_kernel(self._family, self._nu)
+            try:
+                return attr(*args, **kwargs)
+            finally:
+                self._handle.set_kernel(api.KERNEL_GAUSS, 0.0)
+        return call
+
+
 class CombinedGP:
     def __init__(self, script="HX", handle=None, device=0):
         if script not in _SCRIPTS:
@@ -215,3 +236,86 @@ class CombinedGP:
             f = self.h.factors(lp["R_inv"], lp["beta"], y_train)
             rows.append(np.concatenate([row, [lp["beta"]], f, lp["R_inv"].ravel(order="F")]))
         return np.stack(rows)
+
+
+class CombinedGP1D(CombinedGP):
+    """The 1-D script's surface (1D Codes and Designs/1D Combined GP Public.R = D1): Matern(nu)
+    components, every function takes nu the way the script does.
+
+        gp = CombinedGP1D(nu=5)                                   # D1:1080
+        gp.logpost(D_train, theta, y, sigma2, nu)  -> dict(val, beta, R_Inv)     # D1:609-641
+
+    The design is n x 1.  Same device path as the other scripts (ccgp_set_kernel selects the family);
+    prior and Jacobian are D1:636 = ISO:453."""
+
+    def __init__(self, nu=5.0, handle=None, device=0):
+        self.script = "D1"
+        self.cfg = dict(aniso=False, prior=api.PRIOR_ISO, npar=3)
+        self.nu = float(nu)
+        base = handle if handle is not None else api.Handle(device)
+        self.h = _FamilyHandle(base, api.KERNEL_MATERN, self.nu)
+
+    def _with(self, nu):
+        if nu is None or float(nu) == self.nu:
+            return self
+        return CombinedGP1D(nu, handle=self.h._handle)
+
+    @staticmethod
+    def _col(X):
+        X = np.asarray(X, dtype=np.float64)
+        return X.reshape(-1, 1)
+
+    def corr_matrix(self, nu, X, theta):
+        """D1:368-374 corr.matrix(nu, X, theta)."""
+        return self._with(nu).h.corr_matrix(self._col(X), float(theta))
+
+    def corr_vec(self, x, X, theta, nu=None):
+        """D1:383-389 corr.vec(x, X, theta, nu)."""
+        return self._with(nu).h.corr_cross(np.array([[float(x)]]), self._col(X), float(theta))[0]
+
+    def Mixed_corr_matrix(self, D_train, p, theta1, theta2, nu=None):
+        """D1:575-584."""
+        D = self._col(D_train)
+        return self._with(nu).h.mixed_corr_matrix(D, 2, pack_iso(p, theta1, theta2, 1))
+
+    def Mixed_corr_vec(self, x_new, D_train, p, theta1, theta2, nu=None):
+        """D1:591-599."""
+        D = self._col(D_train)
+        return self._with(nu).h.mixed_corr_cross(np.array([[float(x_new)]]), D, 2, pack_iso(p, theta1, theta2, 1))[0]
+
+    def logpost(self, D_train, theta, y, sigma2, nu=None, want_R_Inv=True):
+        """D1:609-641 logpost(D.train, theta, y, sigma2, nu) -> list(val, beta, R.Inv)."""
+        g = self._with(nu)
+        theta = np.asarray(theta, dtype=np.float64).ravel()
+        if theta.size != 3:
+            raise ValueError("D1 logpost takes 3 transformed parameters")
+        r = g.h.logpost(self._col(D_train), y, sigma2, api.PRIOR_ISO, theta, None, want_Rinv=want_R_Inv)
+        return dict(val=r["val"], beta=r["beta"], R_Inv=r["R_inv"] if r["status"] == 0 else None)
+
+    def predict_post(self, x_new, D_train, pars, sigma2, nu=None):
+        """D1:794-812: one frame row (p, theta1, theta2, beta, mean.factor, var.factor1, var.factor2, R.Inv)."""
+        g = self._with(nu)
+        D = self._col(D_train)
+        n = D.shape[0]
+        pars = np.asarray(pars, dtype=np.float64).ravel()
+        r = g.Mixed_corr_vec(x_new, D, pars[0], pars[1], pars[2])
+        R_Inv = pars[5 + 2 * n: 5 + 2 * n + n * n].reshape(n, n, order="F")
+        mean, var = g.h.predict_from_factors(r.reshape(1, -1), pars[3], pars[4:4 + n], pars[4 + n:4 + 2 * n],
+                                             pars[4 + 2 * n], R_Inv, sigma2)
+        return np.array([[mean[0], var[0]]])
+
+    def draws_to_params(self, D_train, draws):
+        draws = np.atleast_2d(np.asarray(draws, dtype=np.float64))
+        return np.stack([pack_iso(r[0], r[1], r[2], 1) for r in draws])
+
+    def prediction_table(self, D_test, draws, D_train, sigma2, y_train):
+        return super().prediction_table(self._col(D_test), draws, self._col(D_train), sigma2, y_train)
+
+    def factors_frame_from_draws(self, draws, D_train, sigma2, y_train):
+        return super().factors_frame_from_draws(draws, self._col(D_train), sigma2, y_train)
+
+    # grids and entropy criteria exist only in the 2-D / emulator scripts
+    def likeli_hyperpars(self, *a, **k):
+        raise NotImplementedError("the 1-D script has no hyperprior grid")
+
+    choose_hyperpars = Entropy = Entropy_batch = Augmented_Mixed_Entropy = likeli_hyperpars

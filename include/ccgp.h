@@ -73,6 +73,16 @@ const char* ccgp_last_error(const ccgp_handle* h);
 const char* ccgp_version(void);
 /* run on a caller-owned hipStream_t (pass NULL to go back to the handle's own stream) */
 int ccgp_set_stream(ccgp_handle* h, void* hip_stream);
+/* correlation family of every component GP for the calls that follow (default Gaussian).
+ * CCGP_KERNEL_GAUSS : R_c[i,j] = exp(-sum_k theta_ck (x_ik - x_jk)^2)     corr.matrix HX:328-337, ANI:351-360
+ * CCGP_KERNEL_MATERN: the 1-D scripts' Matern.corr.func(nu, h, theta) D1:348-351,
+ *                     R_c[i,j] = z^nu K_nu(z) / (Gamma(nu) 2^(nu-1)),  z = 2 sqrt(nu) |x_i - x_j| / theta_c;
+ *                     d must be 1 and a draw is (w_1..w_K, theta_1..theta_K); 1 < nu <= 64 (D1:1080 uses 5).
+ * Replaces corr.matrix(nu, X, theta) D1:368-374, corr.vec D1:383-389 and everything built on them
+ * (Mixed.corr.matrix D1:575-584, logpost D1:609-641, predict.post D1:794-812) through the same entry
+ * points as the Gaussian family; the analytic gradient is Gaussian-only. */
+enum { CCGP_KERNEL_GAUSS = 0, CCGP_KERNEL_MATERN = 1 };
+int ccgp_set_kernel(ccgp_handle* h, int family, double nu);
 /* cap on device scratch used per launch group (default 24 GiB); batches are chunked */
 int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
 /* pre-size scratch so that later _dev calls of this shape never allocate */

@@ -472,6 +472,18 @@ def logpost_1d(D, theta_t, y, sigma2, nu):
     return dict(val=float(val), beta=beta, R_inv=R_inv)
 
 
+def predict_post_1d(x, D, y, p, theta1, theta2, sigma2, nu):
+    """D1:794-812 for one (draw, test point), recomputing the cached per-draw terms as
+    factors.frame would have stored them (D1:760-781)."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    R = _mix(p, corr_matrix_matern(nu, D, theta1), corr_matrix_matern(nu, D, theta2))
+    R_inv = solve_inverse(R)
+    beta = beta_mle(R_inv, y)
+    mf, v1, v2 = factors(R_inv, beta, y)
+    r = _mix(p, corr_vec_matern(x, D, theta1, nu), corr_vec_matern(x, D, theta2, nu))
+    return predict_post_from_factors(r, beta, mf, v1, v2, R_inv, sigma2)
+
+
 def test_function_2d(x, y, code):
     """ANI:330-341: the five bivariate test simulators (needed to make y.train)."""
     if code == 1:

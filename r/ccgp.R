@@ -4,7 +4,7 @@
 # Usage inside any of the reference scripts, AFTER its own function definitions and before
 # its "Simulation starts here" driver block:
 #
-#     ccgp.script <- "HX"          # which script's variant: HX, GV, ISO, ADV, ANI, BSQ
+#     ccgp.script <- "HX"          # which script's variant: HX, GV, ISO, ADV, ANI, BSQ, D1 (1-D, Matern)
 #     source("r/ccgp.R")
 #
 # Everything that calls these functions (Metro, laplace via logpost.val, factors.frame,
@@ -15,7 +15,7 @@ dyn.load(Sys.getenv("CCGP_R_SHIM", "ccgpR.so"))
 
 if (!exists("ccgp.script")) ccgp.script <- "HX"
 .ccgp.aniso <- ccgp.script == "ANI"
-.ccgp.prior <- switch(ccgp.script, HX = 0L, ADV = 0L, GV = 1L, ISO = 2L, BSQ = 2L, ANI = 3L)
+.ccgp.prior <- switch(ccgp.script, HX = 0L, ADV = 0L, GV = 1L, ISO = 2L, BSQ = 2L, ANI = 3L, D1 = 2L)
 
 # (p, theta1, theta2[, lambda]) -> the C-ABI parameter row (w_1, w_2, theta_1k.., theta_2k..)
 .ccgp.row <- function(d, p, theta1, theta2, lambda = NULL) {
@@ -125,4 +125,36 @@ if (ccgp.script == "BSQ") {
   Augmented.Mixed.Entropy <- function(D.old, D.new, p, theta1, theta2, R.old.Inv = NULL)
     -exp(.ccgp.logdet(rbind(as.matrix(D.old), as.matrix(D.new)), p, theta1, theta2) -
          .ccgp.logdet(as.matrix(D.old), p, theta1, theta2))
+}
+
+
+# ---- 1-D script (1D Combined GP Public.R): Matern(nu) components, every function carries nu ---------
+if (ccgp.script == "D1") {
+  .ccgp.matern <- function(nu, expr) {          # select the family for one call, then back to Gaussian
+    .Call("ccgp_R_set_kernel", 1L, as.double(nu))
+    on.exit(.Call("ccgp_R_set_kernel", 0L, 0))
+    force(expr)
+  }
+  corr.matrix <- function(nu, X, theta)                                                   # D1:368-374
+    .ccgp.matern(nu, .Call("ccgp_R_corr_matrix", as.matrix(X), as.double(theta)))
+  corr.vec <- function(x, X, theta, nu)                                                   # D1:383-389
+    .ccgp.matern(nu, as.vector(.Call("ccgp_R_corr_cross", matrix(as.double(x), nrow = 1), as.matrix(X),
+                                     as.double(theta))))
+  Mixed.corr.matrix <- function(D.train, p, theta1, theta2, nu)                           # D1:575-584
+    .ccgp.matern(nu, .Call("ccgp_R_mixed_corr_matrix", as.matrix(D.train), 2L, c(p, 1 - p, theta1, theta2)))
+  Mixed.corr.vec <- function(x.new, D.train, p, theta1, theta2, nu)                       # D1:591-599
+    .ccgp.matern(nu, as.vector(.Call("ccgp_R_mixed_corr_cross", matrix(as.double(x.new), nrow = 1),
+                                     as.matrix(D.train), 2L, c(p, 1 - p, theta1, theta2))))
+  logpost <- function(D.train, theta, y, sigma2, nu)                                      # D1:609-641
+    .ccgp.matern(nu, .ccgp.logpost(D.train, theta, y, sigma2, NULL))
+  predict.post <- function(x.new, D.train, pars, sigma2, nu) {                            # D1:794-812
+    n <- dim(D.train)[1]
+    pars <- as.numeric(pars)
+    r <- Mixed.corr.vec(x.new, D.train, pars[1], pars[2], pars[3], nu = nu)
+    out <- .Call("ccgp_R_predict_from_factors", matrix(r, nrow = 1), pars[4], pars[5:(4 + n)],
+                 pars[(5 + n):(4 + 2 * n)], pars[5 + 2 * n],
+                 matrix(pars[(6 + 2 * n):(5 + 2 * n + n^2)], nrow = n), as.double(sigma2))
+    colnames(out) <- c("mean", "var")
+    out
+  }
 }

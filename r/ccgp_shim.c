@@ -209,6 +209,14 @@ SEXP ccgp_R_mixed_logdet_designs(SEXP Xs, SEXP n, SEXP d, SEXP K, SEXP params) {
   return out;
 }
 
+/* correlation family for the calls that follow: 0 = Gaussian, 1 = Matern(nu) of the 1-D script
+ * (Matern.corr.func, 1D Combined GP Public.R:348-351) */
+SEXP ccgp_R_set_kernel(SEXP family, SEXP nu) {
+  int rc = ccgp_set_kernel(handle(), Rf_asInteger(family), Rf_asReal(nu));
+  warn_rc(rc);
+  return Rf_ScalarInteger(rc);
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_corr_matrix", (DL_FUNC)&ccgp_R_corr_matrix, 2},
     {"ccgp_R_corr_cross", (DL_FUNC)&ccgp_R_corr_cross, 3},
@@ -223,6 +231,7 @@ static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_beta_mle", (DL_FUNC)&ccgp_R_beta_mle, 2},
     {"ccgp_R_sigma2_mle", (DL_FUNC)&ccgp_R_sigma2_mle, 3},
     {"ccgp_R_mixed_logdet_designs", (DL_FUNC)&ccgp_R_mixed_logdet_designs, 5},
+    {"ccgp_R_set_kernel", (DL_FUNC)&ccgp_R_set_kernel, 2},
     {NULL, NULL, 0}};
 
 void R_init_ccgpR(DllInfo* dll) {

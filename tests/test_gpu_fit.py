@@ -68,3 +68,27 @@ def test_speculative_metro_on_the_device_is_the_sequential_chain(handle):
     assert spec["device_batches"] * 4 < seq["device_batches"]
     print("Metro on Qian: %d proposals, sequential %d round trips %.2f s, speculate=5 %d round trips %.2f s"
           % (seq["proposals"], seq["device_batches"], t1 - t0, spec["device_batches"], t2 - t1))
+
+
+def test_one_dimensional_fit_matern(handle):
+    """The 1-D script end to end on the device (BASELINE config 1's surface): driver block D1:1078-1099
+    scaled down -- n.train = 8 points, Matern nu = 5, simulator f2(x) = sin(10 x) (D1:331-339), 50 test
+    sites on [0, 1] -- through laplace + Metro(speculate) + prediction with the Matern family."""
+    from ccgp_amd import fit
+    from ccgp_amd.rsurface import CombinedGP1D
+    X = (np.arange(8) + np.array([0.3, 0.7, 0.5, 0.2, 0.8, 0.4, 0.6, 0.5])) / 8.0       # a Latin hypercube in [0, 1]
+    f = lambda x: np.sin(10.0 * x)
+    D, y = X.reshape(-1, 1), f(X)
+    Dn = np.linspace(0.0, 1.0, 50).reshape(-1, 1)
+    gp = CombinedGP1D(5.0, handle=handle)
+    table = fit.Combined_GP_fit(gp, D, y, Dn, [0.0, 1.5, 0.0], 3000, 600, 0.5, 20, net_samp_size=300, y_new=f(Dn[:, 0]),
+                                sigma2=float(np.var(y, ddof=1)), rng=5, speculate=4)
+    s = fit.comparison_summary(table)
+    print("1-D Matern fit: RMSPE %.3f, coverage %.2f, %d proposals in %d device round trips"
+          % (s["rmspe"], s["coverage"], table["chain"]["proposals"], table["chain"]["device_batches"]))
+    assert s["rmspe"] < 0.35 * np.std(f(Dn[:, 0]))
+    assert s["coverage"] >= 0.8
+    # interpolation at the training sites: the predictive mean reproduces y.train, the variance collapses
+    t = gp.prediction_table(X, table["draws"][:5], X, float(np.var(y, ddof=1)), y)
+    np.testing.assert_allclose(t["mean"], np.tile(y, (5, 1)), atol=1e-6)
+    assert np.all(np.abs(t["var"]) < 1e-6)

@@ -532,3 +532,54 @@ def test_entropy_criteria_over_candidate_designs(handle):
     d9 = rng.random((3, 90, 9))
     np.testing.assert_allclose(gp.Entropy_batch(d9, 0.7, 0.3, 15.0), [orc.entropy(D, 0.7, 0.3, 15.0) for D in d9],
                                rtol=1e-8)
+
+
+def test_config1_matern_1d_surface_vs_oracle(handle):
+    """BASELINE config 1 on the device: the 1-D script's Matern(nu = 5) surface (D1:348-389, D1:575-641,
+    D1:794-812) through ccgp_set_kernel, against the oracle's besselK restatement and the d1 golden
+    fixture.  n = 8, so the correlation matrix is well conditioned only for small scale parameters;
+    tolerance 1e-9 on the log-posterior (cond(R) eps, as in R), 1e-12 on the correlations."""
+    from ccgp_amd.rsurface import CombinedGP1D
+    g = golden("d1_golden.json")
+    X = np.array(g["X"])
+    y = np.array(g["y"])
+    nu = g["nu"]
+    gp = CombinedGP1D(nu, handle=handle)
+    R = gp.corr_matrix(nu, X.reshape(-1, 1), 0.7)
+    np.testing.assert_allclose(R, orc.corr_matrix_matern(nu, X.reshape(-1, 1), 0.7), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(gp.corr_vec(0.37, X, 0.4, nu), orc.corr_vec_matern(0.37, X, 0.4, nu), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(gp.corr_matrix(2.5, X, 0.9), orc.corr_matrix_matern(2.5, X.reshape(-1, 1), 0.9),
+                               rtol=1e-12, atol=1e-15)                      # another smoothness through the same object
+    Rm = gp.Mixed_corr_matrix(X, 0.8, 0.3, 0.9)
+    want = (0.64 * orc.corr_matrix_matern(nu, X.reshape(-1, 1), 0.3) + 0.04 * orc.corr_matrix_matern(nu, X.reshape(-1, 1), 0.9)) / 0.68
+    np.testing.assert_allclose(Rm, want, rtol=1e-12, atol=1e-15)
+    for c in g["cases"]:
+        lp = gp.logpost(X, c["theta_t"], y, c["sigma2"], nu)
+        assert lp["val"] == pytest.approx(c["val"], rel=1e-9)
+        assert lp["beta"] == pytest.approx(c["beta"], rel=1e-8, abs=1e-10)
+        digest_close(lp["R_Inv"], c["R_inv"], 1e-6)      # cond(R) ~ 1e7 for these draws: R.Inv to cond eps
+    # predictions: (draw x test point) tables against D1:794-812 recomputed by the oracle
+    draws = [(0.8, 0.25, 0.6), (0.6, 0.15, 0.9)]
+    xt = np.array([0.11, 0.52, 0.93])
+    s2 = 1.3
+    t = gp.prediction_table(xt, draws, X, s2, y)
+    for i, (p, t1, t2) in enumerate(draws):
+        for j, x in enumerate(xt):
+            m, v = orc.predict_post_1d(x, X.reshape(-1, 1), y, p, t1, t2, s2, nu)
+            assert t["mean"][i, j] == pytest.approx(m, rel=1e-8, abs=1e-10)
+            assert t["var"][i, j] == pytest.approx(v, rel=1e-7, abs=1e-10)
+    # the frame row predict.post consumes (D1:794-812), literally
+    frame = gp.factors_frame_from_draws(draws[:1], X, s2, y)
+    mv = gp.predict_post(0.52, X, frame[0], s2, nu)
+    m, v = orc.predict_post_1d(0.52, X.reshape(-1, 1), y, *draws[0], s2, nu)
+    assert mv[0, 0] == pytest.approx(m, rel=1e-8) and mv[0, 1] == pytest.approx(v, rel=1e-7, abs=1e-10)
+    # the Gaussian family is back for everybody else, and shapes the Matern family does not have fail loudly
+    from ccgp_amd import api
+    handle.set_kernel(api.KERNEL_MATERN, 5.0)
+    with pytest.raises(api.CcgpError):
+        handle.corr_matrix(np.random.default_rng(0).random((5, 2)), 1.0)
+    with pytest.raises(api.CcgpError):
+        handle.set_kernel(api.KERNEL_MATERN, 0.5)
+    handle.set_kernel(api.KERNEL_GAUSS)
+    Dq, _, _, _ = load_qian()
+    np.testing.assert_allclose(handle.corr_matrix(Dq, 0.3), orc.corr_matrix_iso(Dq, 0.3), rtol=1e-12)

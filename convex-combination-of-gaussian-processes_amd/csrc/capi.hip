@@ -101,7 +101,9 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
   DrawView dv{dparams, B, K, d};
   dv.fam = h->fam;
   if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+  if (dv.fam.id == 2 && K != 2)
+    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
   static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
   // the fused evaluators generate Gaussian correlations in registers; any other family goes through
   // the materialised-matrix (blocked) path, where only cov_kernel knows about families
@@ -288,9 +290,9 @@ int ccgp_set_kernel(ccgp_handle* h, int family, double nu) {
     h->fam = ccgp::KernelFamily{};
     return CCGP_OK;
   }
-  if (family != CCGP_KERNEL_MATERN || !(nu > 1.0) || !(nu <= 64.0))
-    return fail(h, CCGP_EINVAL, "ccgp_set_kernel: family must be CCGP_KERNEL_GAUSS or CCGP_KERNEL_MATERN with 1 < nu <= 64");
-  h->fam.id = CCGP_KERNEL_MATERN;
+  if ((family != CCGP_KERNEL_MATERN && family != CCGP_KERNEL_MATERN_SPLINE) || !(nu > 1.0) || !(nu <= 64.0))
+    return fail(h, CCGP_EINVAL, "ccgp_set_kernel: family must be CCGP_KERNEL_GAUSS, or CCGP_KERNEL_MATERN / CCGP_KERNEL_MATERN_SPLINE with 1 < nu <= 64");
+  h->fam.id = family;
   h->fam.nu = nu;
   h->fam.norm = 1.0 / (std::tgamma(nu) * std::pow(2.0, nu - 1.0));
   return CCGP_OK;
@@ -371,7 +373,9 @@ static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* 
   DrawView dv{dp, 1, K, d};
   dv.fam = h->fam;
   if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+  if (dv.fam.id == 2 && K != 2)
+    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
   {
     ScopedTimer t(h, CCGP_T_COV);
     launch_cov_dense(h->stream, gram ? dX : dXn, m, dX, n, d, dv, 0, dout, m);
@@ -581,7 +585,9 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
     DrawView dv{dp, B, K, d};
     dv.fam = h->fam;
     if (dv.fam.id != 0 && d != 1)
-      return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+      return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+    if (dv.fam.id == 2 && K != 2)
+      return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
     Carver tail(static_cast<char*>(h->ws) + Carver::al(blocked_ws_bytes(npad, nbc, ne)));
     BlockedJob job{};
     job.kind = kJobGrad; job.grad = dg; job.Btot = B;
@@ -624,7 +630,9 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   DrawView dv{dp, B, K, d};
   dv.fam = h->fam;
   if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+  if (dv.fam.id == 2 && K != 2)
+    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     launch_small_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst, dgp);
@@ -708,7 +716,9 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     DrawView dv{dp, 1, K, d};
     dv.fam = h->fam;
     if (dv.fam.id != 0 && d != 1)
-      return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+      return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+    if (dv.fam.id == 2 && K != 2)
+      return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
     BlockedJob job{};
     job.kind = kJobInverse; job.Rinv = dR;
     BlockedWs w = blocked_carve(h->ws, npad, 1, nt);
@@ -731,7 +741,9 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     DrawView dv{dp, 1, K, d};
     dv.fam = h->fam;
     if (dv.fam.id != 0 && d != 1)
-      return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+      return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+    if (dv.fam.id == 2 && K != 2)
+      return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
     {
       ScopedTimer t(h, CCGP_T_FUSED);
       launch_small_inverse(h->stream, dX, n, d, dv, 0, dR, dst);
@@ -773,7 +785,9 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
   DrawView dv{dp, 1, K, d};
   dv.fam = h->fam;
   if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+  if (dv.fam.id == 2 && K != 2)
+    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     launch_small_reg_logdet_designs(h->stream, dXs, n, d, dv, B, dld, dst);
@@ -897,7 +911,9 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   DrawView dv{dparams, S, K, d};
   dv.fam = h->fam;
   if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern family is one-dimensional (D1:348-389): d must be 1");
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+  if (dv.fam.id == 2 && K != 2)
+    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
   if (dv.fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
     // blocked path: the m cross-correlation rows ride along as extra tile rows of the sweep
     const int npad = round_up(n, kTile), ne = (m + kTile - 1) / kTile;

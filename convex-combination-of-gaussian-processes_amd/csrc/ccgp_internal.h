@@ -27,7 +27,7 @@ struct TimedSpan {
 
 // correlation family of the component GPs (ccgp_set_kernel)
 struct KernelFamily {
-  int id = 0;        // CCGP_KERNEL_GAUSS | CCGP_KERNEL_MATERN
+  int id = 0;        // CCGP_KERNEL_GAUSS | CCGP_KERNEL_MATERN | CCGP_KERNEL_MATERN_SPLINE
   double nu = 0.0;   // Matern smoothness
   double norm = 0.0; // 1 / (Gamma(nu) 2^(nu-1))
 };
@@ -210,8 +210,18 @@ __device__ __forceinline__ double exp_cov(double x) {
 // reference's expanded form) and then the correlation.  Gaussian (HX:328-356): rate = theta,
 // corr = exp(-dist).  Matern (1-D scripts, D1:348-351): corr = z^nu K_nu(z) / (Gamma(nu) 2^(nu-1)) with
 // z = 2 sqrt(nu) |h| / theta, so rate = 4 nu / theta^2 and z = sqrt(dist); d = 1 only, as in the reference.
-__device__ __forceinline__ double theta_to_rate(const KernelFamily& f, double theta) {
-  return f.id == 0 ? theta : 4.0 * f.nu / (theta * theta);
+// Two-family script (D1F:346-357, D1F:453-462): component 1 Matern as above, component 2 the non-negative
+// cubic spline  1 - 6u^2 + 6u^3 (u <= 1/2), 2(1-u)^3 (u <= 1), 0 beyond, u = |h| / theta: rate = 1/theta^2.
+__device__ __forceinline__ double theta_to_rate(const KernelFamily& f, double theta, int component = 0) {
+  if (f.id == 0) return theta;
+  if (f.id == 2 && component == 1) return 1.0 / (theta * theta);
+  return 4.0 * f.nu / (theta * theta);
+}
+__device__ __forceinline__ double spline_corr(double u2) {
+  const double u = sqrt(u2 > 0.0 ? u2 : 0.0);
+  if (u <= 0.5) return 1.0 - 6.0 * u * u + 6.0 * u * u * u;
+  if (u <= 1.0) { const double v = 1.0 - u; return 2.0 * v * v * v; }
+  return 0.0;
 }
 // z^nu K_nu(z) / (Gamma(nu) 2^(nu-1)) from  K_nu(z) = int_0^inf exp(-z cosh t) cosh(nu t) dt  by the
 // trapezoidal rule (the integrand is entire and decays double-exponentially, so the rule converges
@@ -234,8 +244,10 @@ __device__ inline double matern_corr(const KernelFamily& f, double z2) {
   }
   return exp(f.nu * log(z) - z) * hs * s * f.norm;
 }
-__device__ __forceinline__ double corr_of_dist(const KernelFamily& f, double dist) {
-  return f.id == 0 ? exp_cov(-dist) : matern_corr(f, dist);
+__device__ __forceinline__ double corr_of_dist(const KernelFamily& f, double dist, int component = 0) {
+  if (f.id == 0) return exp_cov(-dist);
+  if (f.id == 2 && component == 1) return spline_corr(dist);
+  return matern_corr(f, dist);
 }
 
 struct ScopedTimer {

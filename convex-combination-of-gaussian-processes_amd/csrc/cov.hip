@@ -33,6 +33,7 @@ struct CovArgs {
   double sigma2, tau2;
   int lower_tiles;  // 1: square, write only tiles with row-tile >= col-tile, pad identity to npad
   int npad;
+  int raw_mix;      // 1: sum w_c^2 r_c without the division by sum w_c^2 (corr.vec.combined as written, D1F:470-480)
 };
 
 // LDS: xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int i0 = tr * kCovRows, j0 = tc * kCovCols;
 
-  for (int e = tid; e < K * d; e += 256) th[e] = FAM == 0 ? a.params[b + (size_t)(K + e) * a.ldp] : theta_to_rate(a.fam, a.params[b + (size_t)(K + e) * a.ldp]);
+  for (int e = tid; e < K * d; e += 256) th[e] = FAM == 0 ? a.params[b + (size_t)(K + e) * a.ldp] : theta_to_rate(a.fam, a.params[b + (size_t)(K + e) * a.ldp], e / d);
   if (tid < K) {
     double w = a.params[b + (size_t)tid * a.ldp];
     w2[tid] = w * w;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   const int cols_valid = a.lower_tiles ? a.npad : a.n;
   constexpr int JW = kCovCols / 4;   // 16 output columns per thread (one row, lane = row)
   const int jl0 = wave * JW;
-  const double inv_sw = 1.0 / sw;    // (sum w_c^2 R_c) / sum w_c^2 as a multiplication (<= 1 ulp apart)
+  const double inv_sw = a.raw_mix ? 1.0 : 1.0 / sw;    // (sum w_c^2 R_c) / sum w_c^2 as a multiplication (<= 1 ulp apart)
   double accs[JW];
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) accs[jj] = 0.0;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
       const double dist = (ur + ub[c * kCovCols + jl0 + jj]) + (-2.0 * sdot[jj]);
-      accs[jj] = fma(wc, (FAM == 0 ? exp_cov(-dist) : matern_corr(a.fam, dist)), accs[jj]);
+      accs[jj] = fma(wc, (FAM == 0 ? exp_cov(-dist) : corr_of_dist(a.fam, dist, c)), accs[jj]);
     }
   }
 #pragma unroll
@@ -147,6 +148,7 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
   a.A = A; a.Bm = Bm; a.m = m; a.n = n; a.d = d;
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = draw;
   a.out = out; a.batch_stride = 0; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
+  a.raw_mix = dv.fam.id == 2 && A != Bm;   // the two-family script's corr.vec.combined never divides (D1F:479)
   dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, 1);
   if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
   else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
@@ -174,6 +176,7 @@ void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const d
   a.A = Xtest; a.Bm = X; a.m = m; a.n = n; a.d = d;
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
   a.out = Abase; a.batch_stride = batch_stride; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
+  a.raw_mix = dv.fam.id == 2;
   dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, nb);
   if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
   else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);

@@ -319,3 +319,60 @@ class CombinedGP1D(CombinedGP):
         raise NotImplementedError("the 1-D script has no hyperprior grid")
 
     choose_hyperpars = Entropy = Entropy_batch = Augmented_Mixed_Entropy = likeli_hyperpars
+
+
+class CombinedGP1DTwoFamilies(CombinedGP1D):
+    """The two-family 1-D script's surface (1D Codes and Designs/1D Combined GP Two Families Public.R =
+    D1F): component 1 Matern(nu, theta1), component 2 the non-negative cubic spline(theta2).
+
+        gp = CombinedGP1DTwoFamilies(nu=5)
+        gp.corr_matrix_combined(X, p, theta1, theta2, nu)          # D1F:453-462
+        gp.corr_vec_combined(x, X, p, theta1, theta2, nu)          # D1F:470-480 -- NOT normalised, as written
+        gp.logpost(D_train, theta, y, sigma2, nu)                  # D1F:576-601
+    """
+
+    def __init__(self, nu=5.0, handle=None, device=0):
+        super().__init__(nu, handle, device)
+        self.script = "D1"       # prior D1F:596 = D1:636
+        self._base = self.h._handle
+        self._matern = CombinedGP1D(nu, handle=self._base)
+        self.h = _FamilyHandle(self._base, api.KERNEL_MATERN_SPLINE, self.nu)
+
+    def _with(self, nu):
+        if nu is None or float(nu) == self.nu:
+            return self
+        return CombinedGP1DTwoFamilies(nu, handle=self._base)
+
+    # single-family pieces
+    def corr_matrix_Matern(self, nu, X, theta):
+        """D1F:426-431."""
+        return self._matern.corr_matrix(nu, X, theta)
+
+    def corr_vec_Matern(self, x, X, theta, nu=None):
+        """D1F:439-444."""
+        return self._matern.corr_vec(x, X, theta, nu)
+
+    def corr_matrix_spline(self, X, theta):
+        """D1F:398-404: the pair with weights (0, 1) is the spline alone."""
+        return self.h.mixed_corr_matrix(self._col(X), 2, np.array([0.0, 1.0, 1.0, float(theta)]))
+
+    def corr_vec_spline(self, x, X, theta):
+        """D1F:412-418."""
+        return self.h.mixed_corr_cross(np.array([[float(x)]]), self._col(X), 2, np.array([0.0, 1.0, 1.0, float(theta)]))[0]
+
+    # the combined model
+    def corr_matrix_combined(self, X, p, theta1, theta2, nu=None):
+        """D1F:453-462."""
+        return self._with(nu).h.mixed_corr_matrix(self._col(X), 2, pack_iso(p, theta1, theta2, 1))
+
+    def corr_vec_combined(self, x, X, p, theta1, theta2, nu=None):
+        """D1F:470-480: p^2 r1 + (1-p)^2 r2 -- the division by p^2 + (1-p)^2 is dead code in the script."""
+        return self._with(nu).h.mixed_corr_cross(np.array([[float(x)]]), self._col(X), 2, pack_iso(p, theta1, theta2, 1))[0]
+
+    Mixed_corr_matrix = corr_matrix_combined
+    Mixed_corr_vec = corr_vec_combined
+
+    def corr_matrix(self, *a, **k):
+        raise AttributeError("the two-family script has corr.matrix.Matern / corr.matrix.spline / corr.matrix.combined")
+
+    corr_vec = corr_matrix

@@ -80,8 +80,14 @@ int ccgp_set_stream(ccgp_handle* h, void* hip_stream);
  *                     d must be 1 and a draw is (w_1..w_K, theta_1..theta_K); 1 < nu <= 64 (D1:1080 uses 5).
  * Replaces corr.matrix(nu, X, theta) D1:368-374, corr.vec D1:383-389 and everything built on them
  * (Mixed.corr.matrix D1:575-584, logpost D1:609-641, predict.post D1:794-812) through the same entry
- * points as the Gaussian family; the analytic gradient is Gaussian-only. */
-enum { CCGP_KERNEL_GAUSS = 0, CCGP_KERNEL_MATERN = 1 };
+ * points as the Gaussian family; the analytic gradient is Gaussian-only.
+ * CCGP_KERNEL_MATERN_SPLINE: the two-family 1-D script (1D Combined GP Two Families Public.R = D1F), K = 2:
+ *                     component 1 Matern(nu, theta_1) as above, component 2 the non-negative cubic spline
+ *                     spline.corr.func(theta_2, h) D1F:346-357.  corr.matrix.combined D1F:453-462 is
+ *                     ccgp_mixed_corr_matrix; corr.vec.combined D1F:470-480 is ccgp_mixed_corr_cross and -- as
+ *                     written there, the division by p^2 + (1-p)^2 sits after the return -- is NOT normalised;
+ *                     predict.post D1F:737-754 (ccgp_predict_batch) uses that same vector. */
+enum { CCGP_KERNEL_GAUSS = 0, CCGP_KERNEL_MATERN = 1, CCGP_KERNEL_MATERN_SPLINE = 2 };
 int ccgp_set_kernel(ccgp_handle* h, int family, double nu);
 /* cap on device scratch used per launch group (default 24 GiB); batches are chunked */
 int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);

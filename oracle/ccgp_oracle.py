@@ -484,6 +484,59 @@ def predict_post_1d(x, D, y, p, theta1, theta2, sigma2, nu):
     return predict_post_from_factors(r, beta, mf, v1, v2, R_inv, sigma2)
 
 
+# --------------------------------------------------------------------------- two-family 1-D script (D1F)
+def spline_corr(theta, h):
+    """D1F:346-357 spline.corr.func(theta, h): the non-negative cubic spline correlation."""
+    u = np.abs(np.asarray(h, dtype=np.float64)) / theta
+    return np.where(u <= 0.5, 1.0 - 6.0 * u ** 2 + 6.0 * u ** 3, np.where(u <= 1.0, 2.0 * (1.0 - u) ** 3, 0.0))
+
+
+def corr_matrix_spline(X, theta):
+    """D1F:398-404."""
+    x = np.asarray(X, dtype=np.float64).reshape(-1)
+    return spline_corr(theta, x[:, None] - x[None, :])
+
+
+def corr_vec_spline(x, X, theta):
+    """D1F:412-418."""
+    return spline_corr(theta, float(x) - np.asarray(X, dtype=np.float64).reshape(-1))
+
+
+def corr_matrix_combined(X, p, theta1, theta2, nu):
+    """D1F:453-462: (p^2 Matern(nu, theta1) + (1-p)^2 spline(theta2)) / (p^2 + (1-p)^2)."""
+    return _mix(p, corr_matrix_matern(nu, X, theta1), corr_matrix_spline(X, theta2))
+
+
+def corr_vec_combined(x, X, p, theta1, theta2, nu):
+    """D1F:470-480 AS WRITTEN: `return(p^2*r1 + (1-p)^2*r2)/(p^2 + (1-p)^2)` returns before the
+    division, so the vector is NOT normalised ("the D1F:479 quirk")."""
+    return p ** 2 * corr_vec_matern(x, X, theta1, nu) + (1.0 - p) ** 2 * corr_vec_spline(x, X, theta2)
+
+
+def logpost_2f(D, theta_t, y, sigma2, nu):
+    """D1F:576-601 (prior D1F:596 = D1:636)."""
+    t = np.asarray(theta_t, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    theta1, theta2 = math.exp(t[0]), math.exp(t[1])
+    p = 1.0 / (1.0 + math.exp(-t[2]))
+    R = corr_matrix_combined(D, p, theta1, theta2, nu)
+    R_inv = solve_inverse(R)
+    beta = beta_mle(R_inv, y)
+    log_like = dmnorm_log(y, beta, (p ** 2 + (1.0 - p) ** 2) * sigma2 * R)
+    val = log_like + log_jacobian(t) + log_prior(t, "D1")
+    return dict(val=float(val), beta=beta, R_inv=R_inv)
+
+
+def predict_post_2f(x, D, y, p, theta1, theta2, sigma2, nu):
+    """D1F:737-754 for one (draw, test point) -- with the un-normalised corr.vec.combined."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    R_inv = solve_inverse(corr_matrix_combined(D, p, theta1, theta2, nu))
+    beta = beta_mle(R_inv, y)
+    mf, v1, v2 = factors(R_inv, beta, y)
+    r = corr_vec_combined(x, D, p, theta1, theta2, nu)
+    return predict_post_from_factors(r, beta, mf, v1, v2, R_inv, sigma2)
+
+
 def test_function_2d(x, y, code):
     """ANI:330-341: the five bivariate test simulators (needed to make y.train)."""
     if code == 1:

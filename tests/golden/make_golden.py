@@ -190,7 +190,29 @@ def make_d1():
     dump("d1_golden.json", out)
 
 
+def make_d1f():
+    """Two-family 1-D script (D1F): Matern(nu = 5, theta1) + cubic spline(theta2) on the same first design."""
+    with open(os.path.join(DATA, "d1_designs_head.txt")) as fh:
+        lines = [ln.strip() for ln in fh if ln.strip()]
+    row = np.array([float(t) for t in lines[1].replace('"', " ").split()[1:]])
+    X = row.reshape(-1, 1)
+    y = np.sin(6.0 * row) + 0.3 * row
+    nu = 5.0
+    out = dict(X=arr(row), y=arr(y), nu=nu, cases=[], xt=[0.07, 0.41, 0.88])
+    out["R_combined"] = matrix_digest(orc.corr_matrix_combined(X, 0.7, 0.5, 0.6, nu))
+    out["r_combined"] = arr(orc.corr_vec_combined(0.41, X, 0.7, 0.5, 0.6, nu))       # un-normalised (D1F:479)
+    out["R_spline"] = matrix_digest(orc.corr_matrix_spline(X, 0.45))
+    for theta_t, s2 in (([-0.5, -0.4, 0.5], 1.0), ([-0.9, -0.2, 1.5], 0.4)):
+        lp = orc.logpost_2f(X, theta_t, y, s2, nu)
+        th1, th2, p = math.exp(theta_t[0]), math.exp(theta_t[1]), 1.0 / (1.0 + math.exp(-theta_t[2]))
+        pred = [orc.predict_post_2f(x, X, y, p, th1, th2, s2, nu) for x in out["xt"]]
+        out["cases"].append(dict(theta_t=theta_t, sigma2=s2, val=lp["val"], beta=lp["beta"],
+                                 R_inv=matrix_digest(lp["R_inv"]), pred_mean=[float(m) for m, _ in pred],
+                                 pred_var=[float(v) for _, v in pred]))
+    dump("d1f_golden.json", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hx", "ani", "adv", "gv", "d1"]
+    which = sys.argv[1:] or ["hx", "ani", "adv", "gv", "d1", "d1f"]
     for w in which:
         globals()["make_" + w]()

@@ -583,3 +583,34 @@ def test_config1_matern_1d_surface_vs_oracle(handle):
     handle.set_kernel(api.KERNEL_GAUSS)
     Dq, _, _, _ = load_qian()
     np.testing.assert_allclose(handle.corr_matrix(Dq, 0.3), orc.corr_matrix_iso(Dq, 0.3), rtol=1e-12)
+
+
+def test_two_family_1d_surface_vs_fixture(handle):
+    """The two-family 1-D script (D1F) on the device: Matern(nu = 5) + cubic spline through
+    CCGP_KERNEL_MATERN_SPLINE, against the d1f fixture (oracle restatement of D1F:346-601, 737-754),
+    including the un-normalised corr.vec.combined of D1F:479 and the predictions built on it."""
+    from ccgp_amd.rsurface import CombinedGP1DTwoFamilies
+    g = golden("d1f_golden.json")
+    X, y, nu = np.array(g["X"]), np.array(g["y"]), g["nu"]
+    gp = CombinedGP1DTwoFamilies(nu, handle=handle)
+    digest_close(gp.corr_matrix_spline(X, 0.45), g["R_spline"], 1e-13)
+    np.testing.assert_allclose(gp.corr_vec_spline(0.41, X, 0.45), orc.corr_vec_spline(0.41, X, 0.45), rtol=1e-13, atol=1e-16)
+    np.testing.assert_allclose(gp.corr_matrix_Matern(nu, X, 0.5), orc.corr_matrix_matern(nu, X.reshape(-1, 1), 0.5), rtol=1e-12)
+    digest_close(gp.corr_matrix_combined(X, 0.7, 0.5, 0.6, nu), g["R_combined"], 1e-12)
+    np.testing.assert_allclose(gp.corr_vec_combined(0.41, X, 0.7, 0.5, 0.6, nu), g["r_combined"], rtol=1e-12)
+    xt = np.array(g["xt"])
+    for c in g["cases"]:
+        lp = gp.logpost(X, c["theta_t"], y, c["sigma2"], nu)
+        assert lp["val"] == pytest.approx(c["val"], rel=1e-10)
+        assert lp["beta"] == pytest.approx(c["beta"], rel=1e-9, abs=1e-12)
+        digest_close(lp["R_Inv"], c["R_inv"], 1e-9)
+        t = c["theta_t"]
+        draw = (1.0 / (1.0 + math.exp(-t[2])), math.exp(t[0]), math.exp(t[1]))
+        tab = gp.prediction_table(xt, [draw], X, c["sigma2"], y)
+        np.testing.assert_allclose(tab["mean"][0], c["pred_mean"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(tab["var"][0], c["pred_var"], rtol=1e-9, atol=1e-12)
+    from ccgp_amd import api
+    handle.set_kernel(api.KERNEL_MATERN_SPLINE, 5.0)
+    with pytest.raises(api.CcgpError):                       # the pair is K = 2 by definition
+        handle.mixed_corr_matrix(X.reshape(-1, 1), 3, np.array([0.3, 0.3, 0.4, 0.5, 0.6, 0.7]))
+    handle.set_kernel(api.KERNEL_GAUSS)

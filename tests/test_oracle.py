@@ -185,3 +185,26 @@ def test_config1_matern_plumbing():
     for c in g["cases"]:
         lp = orc.logpost_1d(X, c["theta_t"], np.array(g["y"]), c["sigma2"], g["nu"])
         assert lp["val"] == pytest.approx(c["val"], rel=1e-12)
+
+
+def test_two_family_script_restatement_and_fixture():
+    """D1F: Matern + non-negative cubic spline.  Known answers of the spline (D1F:346-357), the un-normalised
+    corr.vec.combined (D1F:479) and the committed fixture."""
+    g = golden("d1f_golden.json")
+    X = np.array(g["X"]).reshape(-1, 1)
+    y = np.array(g["y"])
+    assert float(orc.spline_corr(2.0, 0.0)) == 1.0
+    assert float(orc.spline_corr(2.0, 1.0)) == pytest.approx(1 - 6 * 0.25 + 6 * 0.125)      # u = 1/2, first branch
+    assert float(orc.spline_corr(2.0, 1.5)) == pytest.approx(2 * 0.25 ** 3)                 # u = 3/4, second branch
+    assert float(orc.spline_corr(2.0, 2.5)) == 0.0
+    Rs = orc.corr_matrix_spline(X, 0.45)
+    assert np.all(np.linalg.eigvalsh(Rs) > 0) and np.allclose(np.diag(Rs), 1.0)
+    p, t1, t2, nu = 0.7, 0.5, 0.6, g["nu"]
+    r = orc.corr_vec_combined(0.41, X, p, t1, t2, nu)
+    np.testing.assert_allclose(r, g["r_combined"], rtol=1e-13)
+    normalised = r / (p ** 2 + (1 - p) ** 2)
+    np.testing.assert_allclose(normalised, (p ** 2 * orc.corr_vec_matern(0.41, X, t1, nu) + (1 - p) ** 2 *
+                                            orc.corr_vec_spline(0.41, X, t2)) / (p ** 2 + (1 - p) ** 2), rtol=1e-14)
+    for c in g["cases"]:
+        lp = orc.logpost_2f(X, c["theta_t"], y, c["sigma2"], nu)
+        assert lp["val"] == pytest.approx(c["val"], rel=1e-12)

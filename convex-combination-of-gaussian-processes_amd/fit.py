@@ -351,6 +351,25 @@ def Combined_GP_fit(gp, D_train, y_train, D_new, start, N_max, samp_size, alpha_
     return table
 
 
+def write_results_table(path, table, D_test, input_names, comparators=("single", "CGP")):
+    """The file compare.GP's result is written to (`write.table(as.matrix(Comp.obj), file = fname)`,
+    GV:759-761): the test inputs, y.hat / Quant / LL / UL of the Combined GP, the comparator models'
+    columns (ordinary kriging and CGP are out of scope here: NA) and y.true -- same columns, order and
+    number format as `Results/Size 50 Results 1.txt`, so the two files can be diffed."""
+    from .tables import write_table
+    D_test = np.asarray(D_test, dtype=np.float64)
+    m = D_test.shape[0]
+    cols = [D_test, table["y_hat"][:, None], table["quant"][:, None], table["LL"][:, None], table["UL"][:, None]]
+    names = list(input_names) + ["y.hat.Combined", "Quant.Combined", "LL.Combined", "UL.Combined"]
+    for c in comparators:
+        cols.append(np.full((m, 3), np.nan))
+        names += ["y.hat.%s" % c, "LL.%s" % c, "UL.%s" % c]
+    cols.append(np.asarray(table["y_true"], dtype=np.float64)[:, None])
+    names.append("y.true")
+    write_table(path, np.hstack(cols), names)
+    return names
+
+
 def comparison_summary(table):
     """Comparison.Summary's Combined-GP figures (ANI:703-721): RMSPE and interval coverage."""
     e = table["y_true"] - table["y_hat"]

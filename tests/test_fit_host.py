@@ -80,3 +80,24 @@ def test_speculative_metro_is_the_sequential_chain_bit_for_bit(m):
     assert calls.count(2 ** m - 1) == spec["device_batches"]   # every chain round trip carries the whole tree
     assert spec["device_batches"] <= -(-seq["proposals"] // m) + 1 < seq["device_batches"]
     assert n_seq_calls > len(calls)
+
+
+def test_results_table_has_the_reference_layout(tmp_path):
+    """fit.write_results_table writes compare.GP's table in the layout of the reference's recorded
+    `Size 50 Results 1.txt` (GV:759-761): same header, comparator columns NA."""
+    import os
+    from conftest import DATA
+    from ccgp_amd.tables import read_table
+    ref_names, ref = read_table(os.path.join(DATA, "gv", "results_50_1.txt"))
+    m = 4
+    table = dict(y_hat=np.arange(m) + 0.5, quant=np.full(m, 0.5), LL=np.arange(m) - 1.0, UL=np.arange(m) + 2.0,
+                 y_true=np.arange(m) + 0.25)
+    path = os.path.join(tmp_path, "res.txt")
+    names = fit.write_results_table(path, table, ref[:m, :9], ref_names[:9])
+    assert names == ref_names
+    got_names, got = read_table(path)
+    assert got_names == ref_names and got.shape == (m, len(ref_names))
+    np.testing.assert_array_equal(got[:, :9], ref[:m, :9])
+    np.testing.assert_array_equal(got[:, 9], table["y_hat"])
+    assert np.isnan(got[:, 13:19]).all()
+    np.testing.assert_array_equal(got[:, 19], table["y_true"])

@@ -47,3 +47,23 @@ def test_write_table_roundtrip(tmp_path):
     np.testing.assert_array_equal(a, b)
     with open(p, "rb") as fh:
         assert fh.read().count(b"\r\n") == 3
+
+
+def test_results_table_of_the_reference_round_trips_byte_for_byte(tmp_path):
+    """Ground Vibrations Emulator/Results/Size 50 Results 1.txt (write.table(as.matrix(Comp.obj)), GV:760-761,
+    the only output the reference records): read it, write it back, same bytes -- so a results table
+    produced here is diff-able against the reference's."""
+    src = os.path.join(DATA, "gv", "results_50_1.txt")
+    names, a, rows = read_table(src, with_row_names=True)
+    assert a.shape == (150, len(names)) and names[:3] == ["slope", "angle", "top.layer3"]
+    assert rows[:5] == ["1", "2", "3", "4", "7"]                  # the test set is a subset of a larger frame
+    assert "y.hat.Combined" in names and "y.true" in names
+    out = os.path.join(tmp_path, "back.txt")
+    write_table(out, a, names, rows)
+    with open(src, "rb") as f1, open(out, "rb") as f2:
+        assert f1.read() == f2.read()
+    # the summary the recorded run implies (SURVEY 6): RMSPE 2.72, 95 % coverage 0.97
+    yt, yh = a[:, names.index("y.true")], a[:, names.index("y.hat.Combined")]
+    lo, hi = a[:, names.index("LL.Combined")], a[:, names.index("UL.Combined")]
+    assert abs(np.sqrt(np.mean((yt - yh) ** 2)) - 2.72) < 0.01
+    assert abs(np.mean((yt >= lo) & (yt <= hi)) - 0.973) < 0.005

@@ -169,8 +169,15 @@ class Handle:
     def synchronize(self):
         self._chk(lib().ccgp_synchronize(self._h))
 
-    def enable_timing(self, on=True):
-        self._chk(lib().ccgp_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, on=True, only=None):
+        """Bracket launch groups with HIP events on their stream.  only = names from TIMING_NAMES to
+        restrict the events to (each timed launch costs two event records)."""
+        mask = 1 if on else 0
+        if on and only is not None:
+            mask = 0
+            for name in only:
+                mask |= 1 << (1 + TIMING_NAMES.index(name))
+        self._chk(lib().ccgp_enable_timing(self._h, mask))
 
     def get_timing(self):
         out = {}

@@ -47,7 +47,7 @@ struct ccgp_handle {
   size_t stage_bytes = 0;
   std::string err;
   ccgp::KernelFamily fam;
-  bool timing = false;
+  unsigned timing = 0;   // bit i set: launch groups with id i are bracketed by HIP events
   std::vector<ccgp::TimedSpan> spans;
   size_t spans_used = 0;
 };
@@ -255,7 +255,7 @@ struct ScopedTimer {
   TimedSpan* sp = nullptr;
   hipStream_t st;
   ScopedTimer(ccgp_handle* hh, int id, hipStream_t stream = nullptr) : h(hh), st(stream ? stream : hh->stream) {
-    if (!h->timing) return;
+    if (!((h->timing >> id) & 1u)) return;
     if (h->spans_used == h->spans.size()) {
       TimedSpan t{};
       (void)hipEventCreate(&t.e0);

@@ -205,6 +205,7 @@ enum {
   CCGP_T_FUSED = 5,    /* small-n fused in-LDS evaluator    */
   CCGP_T_COUNT = 6
 };
+/* on = 0: off; 1: every id; otherwise a mask with bit (1 + id) set for each id to time */
 int ccgp_enable_timing(ccgp_handle* h, int on);
 int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches);
 

@@ -92,3 +92,25 @@ def test_one_dimensional_fit_matern(handle):
     t = gp.prediction_table(X, table["draws"][:5], X, float(np.var(y, ddof=1)), y)
     np.testing.assert_allclose(t["mean"], np.tile(y, (5, 1)), atol=1e-6)
     assert np.all(np.abs(t["var"]) < 1e-6)
+
+
+def test_anisotropic_2d_fit(handle):
+    """The 2-D anisotropic script end to end (driver block ANI:779-804 scaled down): maximin-14 design,
+    simulator f3 (ANI:337), four transformed parameters (psi1, psi2, phi, zeta), prior ANI:462."""
+    from ccgp_amd import fit
+    from ccgp_amd.rsurface import CombinedGP
+    from conftest import load_maximin
+    from oracle import ccgp_oracle as orc
+    D = load_maximin(14)
+    y = np.array([orc.test_function_2d(a, b, 3) for a, b in D])
+    g = np.linspace(0.05, 0.95, 6)
+    Dn = np.array([[a, b] for a in g for b in g])
+    yn = np.array([orc.test_function_2d(a, b, 3) for a, b in Dn])
+    gp = CombinedGP("ANI", handle=handle)
+    table = fit.Combined_GP_fit(gp, D, y, Dn, [0.0, 0.0, 0.0, 0.0], 3000, 500, 0.5, 20, net_samp_size=250, y_new=yn,
+                                sigma2=float(np.var(y, ddof=1)), rng=11, speculate=4)
+    s = fit.comparison_summary(table)
+    print("2-D anisotropic fit on maximin-14: RMSPE %.3f (sd of y %.3f), coverage %.2f" % (s["rmspe"], np.std(yn), s["coverage"]))
+    assert table["draws"].shape == (250, 4) and np.all(table["draws"][:, 1:] > 0)
+    assert s["rmspe"] < 0.6 * np.std(yn)
+    assert s["coverage"] >= 0.75

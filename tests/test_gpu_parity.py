@@ -440,6 +440,38 @@ def test_n4096_against_lapack_and_invariances(handle):
     assert beta[0] == pytest.approx(b0, rel=1e-7, abs=1e-10)
 
 
+def test_beyond_the_benchmark_size_n8192_ragged(handle):
+    """Twice config 4's order and not a multiple of the tile: n = 8100 (64 block columns, ragged last
+    tile), d = 3, K = 2, two draws + prediction at 130 sites (two extra tile rows), against LAPACK."""
+    import scipy.linalg as sla
+    n, d, K, m = 8100, 3, 2, 130
+    X, y = synthetic_design(n, d, seed=99)
+    Xt = np.random.default_rng(5).random((m, d))
+    P = np.array([[0.6, 0.4, 2.0, 3.0, 4.0, 150.0, 180.0, 200.0],
+                  [0.3, 0.7, 1.0, 1.5, 2.5, 120.0, 140.0, 260.0]])
+    ll, beta, st = handle.loglik_batch(X, y, K, P, 1.3, 0, 0.0)
+    mean, var, beta_p, st_p = handle.predict_batch(X, y, K, P[:1], Xt, 1.3)
+    assert not st.any() and not st_p.any()
+    w, Th = orc.unpack_params(P[0], K, d)
+    R = orc.mixed_corr_matrix_general(X, w, Th)
+    L = sla.cholesky(R, lower=True)
+    zy = sla.solve_triangular(L, y, lower=True)
+    z1 = sla.solve_triangular(L, np.ones(n), lower=True)
+    b0 = (z1 @ zy) / (z1 @ z1)
+    c = 1.3 * np.sum(w ** 2)
+    want = -0.5 * (n * math.log(2 * math.pi) + n * math.log(c) + 2 * np.log(np.diag(L)).sum()
+                   + np.sum((zy - b0 * z1) ** 2) / c)
+    assert ll[0] == pytest.approx(want, rel=1e-9)
+    assert beta[0] == pytest.approx(b0, rel=1e-7, abs=1e-10) and beta_p[0] == beta[0]
+    # predict.post (HX:667-670) in the factor's metric for a few sites
+    r = sum(w[c] ** 2 * np.exp(-(((Xt[:5, None, :] - X[None, :, :]) ** 2) * Th[c]).sum(axis=2)) for c in range(K)) / np.sum(w ** 2)
+    Wt = sla.solve_triangular(L, r.T, lower=True)          # n x 5:  L^-1 r(x_t)
+    zr = zy - b0 * z1
+    np.testing.assert_allclose(mean[0, :5], b0 + zr @ Wt, rtol=1e-8, atol=1e-10)
+    want_var = 1.3 * (1.0 - np.sum(Wt * Wt, axis=0) + (1.0 - z1 @ Wt) ** 2 / (z1 @ z1))
+    np.testing.assert_allclose(var[0, :5], want_var, rtol=1e-6, atol=1e-9)
+
+
 # ------------------------------------------------------------------------------- failure detection
 def test_non_positive_definite_maps_to_na(handle):
     """HX:454-455: a singular R gives NA, not an abort.  A duplicated design point makes R

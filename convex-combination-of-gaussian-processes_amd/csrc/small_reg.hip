@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
   for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
     for (int aa = bb; aa < NB; ++aa) M[aa][bb] = 0.0;
+  int rowi[NB];   // clamped row of every row block (padding rows repeat row n-1; they are overwritten below)
+#pragma unroll
+  for (int aa = 0; aa < NB; ++aa) rowi[aa] = min(ty + G * aa, n - 1);
   for (int q = 0; q < K; ++q) {
     const double wq = w2[q];
 #pragma unroll
@@ -162,11 +165,18 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
       for (int aa = 0; aa < NB; ++aa) sdot[aa][0] = sdot[aa][1] = 0.0;
       const int c0 = min(tx + G * bb0, n - 1), c1 = min(tx + G * (bb0 + 1), n - 1);
       for (int k = 0; k < d; ++k) {
+        // all LDS reads of this dimension first (one round trip), then the arithmetic: left to itself the
+        // compiler reuses one register pair for the row coordinates and waits after every single read
+        const double* xk = xs + k * n;
+        double xrow[NB];
+#pragma unroll
+        for (int aa = bb0; aa < NB; ++aa) xrow[aa] = xk[rowi[aa]];
         const double tq = th[q * d + k];
-        const double xc0 = xs[k * n + c0], xc1 = xs[k * n + c1];
+        const double xc0 = xk[c0], xc1 = xk[c1];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int aa = bb0; aa < NB; ++aa) {
-          const double xr = xs[k * n + min(ty + G * aa, n - 1)] * tq;
+          const double xr = xrow[aa] * tq;
           sdot[aa][0] = fma(xr, xc0, sdot[aa][0]);
           if (aa >= bb0 + 1 && bb0 + 1 < NB) sdot[aa][1] = fma(xr, xc1, sdot[aa][1]);
         }

@@ -495,6 +495,36 @@ def test_non_positive_definite_maps_to_na(handle):
     assert stb[0] > 0 and math.isnan(llb[0])
 
 
+def test_chunked_batches_equal_one_pass(handle):
+    """A batch larger than the device workspace is processed in chunks (ccgp_set_workspace_limit): same
+    values, same per-draw status, ragged last chunk, a singular draw in the middle of a chunk."""
+    X, y = synthetic_design(300, 3, seed=21)
+    Xt = np.random.default_rng(2).random((40, 3))
+    rng = np.random.default_rng(8)
+    P = np.stack([orc.params_from_iso(rng.uniform(0.3, 0.9), rng.uniform(1, 3), rng.uniform(8, 20), 3) for _ in range(7)])
+    Xs = X.copy()
+    ll0, b0, st0 = handle.loglik_batch(Xs, y, 2, P, 1.0, 0, 0.0)
+    m0, v0, _, _ = handle.predict_batch(Xs, y, 2, P, Xt, 1.0)
+    try:
+        handle.set_workspace_limit(4 << 20)                 # ~2 matrices of 384 x 512 doubles per pass
+        ll1, b1, st1 = handle.loglik_batch(Xs, y, 2, P, 1.0, 0, 0.0)
+        m1, v1, _, _ = handle.predict_batch(Xs, y, 2, P, Xt, 1.0)
+        Xd = X.copy()
+        Xd[120] = Xd[7]                                     # exactly singular: pivot 121 is 0 up to rounding
+        lld, _, std = handle.loglik_batch(Xd, y, 2, P, 1.0, 0, 0.0)
+    finally:
+        handle.set_workspace_limit(24 << 30)
+    np.testing.assert_array_equal(ll0, ll1)
+    np.testing.assert_array_equal(b0, b1)
+    np.testing.assert_array_equal(st0, st1)
+    np.testing.assert_array_equal(m0, m1)
+    np.testing.assert_array_equal(v0, v1)
+    # the pivot of the duplicated row is 0 in exact arithmetic: it comes out non-positive (status = its
+    # 1-based index, NaN value -- the reference's NA) or, for some draws, as a positive rounding residue
+    assert set(std.tolist()) <= {0, 121} and np.count_nonzero(std) >= 4
+    assert np.all(np.isnan(lld[std > 0]))
+
+
 def test_edge_shapes(handle):
     D, y, Dt, _ = load_qian()
     ll, beta, st = handle.loglik_batch(D, y, 2, np.empty((0, 10)), 1.0)

@@ -303,7 +303,8 @@ CCGP_DEFINE_GEMM(chol_trsm_s4_kernel, 1, 4, 3)
 // Strip count for an update launch: minimise ceil(workgroups / resident slots) x time per
 // workgroup.  Slots per chip (2 / 3 / 3 workgroups per CU by LDS) and the relative per-flop
 // efficiency of the narrower strips (1 / 0.80 / 0.65) were fitted to per-launch rocprof
-// timings on MI355X (profiles/r01c_strip_selection.md): within 1.3 % of the per-launch optimum.
+// timings on MI355X (profiles/r01c_strip_selection.md); with the final round-1 kernels the selection is at
+// the per-launch optimum of the three pinned runs within noise (profiles/r01j_strip_table.md).
 static int pick_strips(int tiles) {
   const int slots[3] = {512, 768, 768};
   const double eff[3] = {1.0, 0.80, 0.65};

@@ -143,13 +143,17 @@ def update_kernel_flops(n, diag_tiles=True):
     return sum(j * t3 * ((nt - 1 - j) + (0.5 if diag_tiles else 0.0)) for j in range(1, nt))
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, matrices_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (counters cannot
-    be read from inside the process; collected separately exactly as the MI355X guide prescribes)."""
+    be read from inside the process; collected separately exactly as the MI355X guide prescribes).
+    Only quoted when the passes were collected with the same number of matrices per launch."""
     path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     try:
         with open(path) as fh:
-            return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/" + PMC_TRAFFIC_FILE
+            rec = json.load(fh)
+        if rec.get("matrices_per_launch", 64) != matrices_per_launch:
+            return None, None
+        return rec["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/" + PMC_TRAFFIC_FILE
     except Exception:
         return None, None
 
@@ -186,7 +190,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2"])
-    ap.add_argument("--evals-per-gpu", type=int, default=64)
+    ap.add_argument("--evals-total", type=int, default=512,
+                    help="cfg4: size of the hyperparameter grid, sharded over the GPUs (BASELINE config 4: 512)")
+    ap.add_argument("--evals-per-gpu", type=int, default=0,
+                    help="cfg4: fixed per-GPU slice instead of a fixed grid (weak scaling; experiments only)")
+    ap.add_argument("--strips", type=int, default=0, choices=[0, 1, 2],
+                    help="pin the update kernel's column-strip count (ccgp_set_option; 0 = per-launch choice)")
+    ap.add_argument("--ws-limit-gib", type=float, default=0.0,
+                    help="cap the device scratch (ccgp_set_workspace_limit) to force multi-chunk batches")
     ap.add_argument("--n", type=int, default=4096, help="cfg4 matrix order (parity/debug runs only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -222,12 +233,13 @@ def main():
 
     mode, tau2 = api.MEAN_PROFILE_BETA, 0.0
     if args.workload == "cfg4":
-        total = args.evals_per_gpu * world
+        weak = args.evals_per_gpu > 0
+        total = args.evals_per_gpu * world if weak else args.evals_total
         X, y, P, K = cfg4_inputs(total, n=args.n)
         sigma2 = 1.0
         lo, hi = shard.shard_bounds(total, rank, world)
-        wl_name = "cfg4: synthetic maximin-LHS 5-D design n=%d, K=3 anisotropic components, %d draws/GPU" % (
-            args.n, args.evals_per_gpu)
+        wl_name = "cfg4: synthetic maximin-LHS 5-D design n=%d, K=3 anisotropic components, %d-point hyperparameter grid%s" % (
+            args.n, total, " (%d per GPU)" % args.evals_per_gpu if weak else " sharded over the GPUs")
     else:
         X, y, P, K, sigma2 = cfg2_inputs()
         mode, tau2 = api.MEAN_ZERO_PLUS_TAU2, 50.0 ** 2
@@ -256,6 +268,10 @@ def main():
 
     h = api.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.strips:
+        h.set_option(api.OPT_UPDATE_STRIPS, args.strips)
+    if args.ws_limit_gib > 0:
+        h.set_workspace_limit(int(args.ws_limit_gib * 2 ** 30))
     h.reserve(n, d, K, max(B, 1), 0)
 
     def step():
@@ -306,7 +322,7 @@ def main():
             "metric": "GP log-lik evals/sec (n x n fp64, batched over hyperpar grid)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak" if args.workload == "cfg4" else "strong",
+            "scaling": "weak" if (args.workload == "cfg4" and args.evals_per_gpu > 0) else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name, "n": n, "d": d, "K": K, "evals_total": total,
                        "evals_per_gpu": B, "parallelism": "grid sharded over %d GPU(s), one all-gather%s" % (
@@ -321,7 +337,7 @@ def main():
             split = timing.get("update_diag", (0.0, 0))[1] > 0        # diagonal tiles launched separately
             flops = update_kernel_flops(n, diag_tiles=not split) * B * args.steps   # this rank's launches
             ach = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-            traffic, traffic_src = pmc_traffic("chol_update") if (n == 4096 and B == 64) else (None, None)
+            traffic, traffic_src = pmc_traffic("chol_update", B) if n == 4096 else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",

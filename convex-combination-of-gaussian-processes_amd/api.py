@@ -18,6 +18,7 @@ MEAN_ZERO_PLUS_TAU2 = 1
 PRIOR_INVGAMMA, PRIOR_GV, PRIOR_ISO, PRIOR_ANI = 0, 1, 2, 3
 T_COV, T_UPDATE, T_DIAG, T_TRSM, T_SOLVE, T_FUSED = range(6)
 KERNEL_GAUSS, KERNEL_MATERN, KERNEL_MATERN_SPLINE = 0, 1, 2
+OPT_UPDATE_STRIPS, OPT_SMALL_LDS = 0, 1
 TIMING_NAMES = ("cov", "update", "diag", "trsm", "solve", "fused")
 
 _dp = POINTER(c_double)
@@ -32,6 +33,7 @@ SIGNATURES = {
     "ccgp_set_stream": (c_int, [c_void_p, c_void_p]),
     "ccgp_set_kernel": (c_int, [c_void_p, c_int, c_double]),
     "ccgp_set_workspace_limit": (c_int, [c_void_p, c_size_t]),
+    "ccgp_set_option": (c_int, [c_void_p, c_int, c_int]),
     "ccgp_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "ccgp_synchronize": (c_int, [c_void_p]),
     "ccgp_corr_matrix": (c_int, [c_void_p, _dp, c_int, c_int, _dp, _dp]),
@@ -162,6 +164,10 @@ class Handle:
 
     def set_workspace_limit(self, nbytes):
         self._chk(lib().ccgp_set_workspace_limit(self._h, int(nbytes)))
+
+    def set_option(self, option, value):
+        """Measurement switches of include/ccgp.h (OPT_UPDATE_STRIPS, OPT_SMALL_LDS)."""
+        self._chk(lib().ccgp_set_option(self._h, int(option), int(value)))
 
     def reserve(self, n, d, K, B, m=0):
         self._chk(lib().ccgp_reserve(self._h, n, d, K, B, m))

@@ -10,9 +10,13 @@
 // Z' = [y 1]' L^-T, i.e. the forward substitution L z = b is done -- no separate solve
 // pass over the 4n^2 B factor.  A last tiny kernel turns Z and the pivots into what the
 // reference's dmnorm / beta.MLE return (HX:458-460, HX:570).  Left-looking because every tile is then
-// written once and the panels it re-reads are shared through L2 / Infinity Cache: HBM
-// traffic is ~2 x 4n^2 B per matrix instead of the right-looking 8n^3/(3 nb) B, so the
-// trailing update is MFMA-bound, not HBM-bound.
+// WRITTEN once (the right-looking form rewrites the whole trailing matrix per block column).  The reads
+// stay: tile (i, j) streams its own row panel L_i,0..j-1 from HBM and shares the column panel L_j,0..j-1
+// with the other tiles of its matrix through that XCD's L2, so the algorithmic read traffic is
+// sum_j (nt - j) j 128 KiB = 0.7 GB per n = 4096 matrix (~ 8 n^3 / (6 nb) B), 1.4 GB per launch of 64
+// matrices at mid sweep; measured 2.4 GB per launch with strips (PMC, profiles/r01j/pmc_traffic.json).
+// At 128-wide tiles that is 16 flop per HBM byte against a machine balance of ~10: MFMA-bound, with
+// HBM at a third of its peak.
 //
 // MFMA: v_mfma_f64_16x16x4_f64.  Operand lane map (one f64 per lane):
 //   A[i = lane&15][k = lane>>4],  B[k = lane>>4][j = lane&15],
@@ -232,29 +236,183 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
   }
 }
 
+
+// ---- diagonal tile of the update, fused with the right-hand-side rows ---------------------------
+// The diagonal tile T_jj = A_jj - L_j L_j' (L_j = the finished panel, rows j of block columns < j)
+// needs only its lower triangle: 36 of its 64 16 x 16 sub-tiles, and both GEMM operands are the SAME
+// panel.  The right-hand-side rows (y', 1' and 14 zero rows below the matrix) need  b_j' - Z L_j'  against
+// that same panel: 8 more sub-tiles.  One workgroup does both: it stages the panel ONCE per k-stage
+// (16 KB + 2 KB for the 16 right-hand-side rows instead of 32 KB) and each wave accumulates 11 sub-tiles
+// (block rows w and 7 - w of the triangle: 9 sub-tiles whatever w; plus right-hand-side columns 2w, 2w+1)
+// against 16 for a full tile.  Before round 2 the diagonal tile ran as a full tile and the right-hand
+// sides as a separate "thin" workgroup that occupied a full slot for a whole tile time: at the late
+// block columns (few tile rows per matrix) half of the resident workgroups did almost no arithmetic.
+__device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, const double* Tp, int ld,
+                                              int Kdim, double* C, double* Ct) {
+  constexpr int BKs = 16;
+  constexpr int TR = 16;                                // right-hand-side rows staged
+  constexpr int STAGE = BKs * kTile + BKs * TR;         // doubles per stage
+  constexpr int NS = 11;                                // sub-tiles per wave: 9 of the triangle + 2 right-hand-side
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int rA = wave, rB = 7 - wave;
+
+  d4 acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // slot -> column block: slots 0..wave belong to block row rA (cb = s), the rest of 0..8 to block row
+  // rB (cb = s - wave - 1); slots 9, 10 are the right-hand-side rows against column blocks 2w, 2w + 1
+  int cbs[NS];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) cbs[s] = s <= wave ? s : s - wave - 1;
+  cbs[9] = 2 * wave;
+  cbs[10] = 2 * wave + 1;
+
+  const int psrc = ((((lane >> 3) ^ (wave & 1)) << 4) + ((lane & 7) << 1));
+  const double* pQ = Qp + psrc + (size_t)wave * ld;                       // wave w stages columns k = w + 4q
+  const double* pT = Tp + ((lane & 7) << 1) + (size_t)(8 * wave + (lane >> 3)) * ld;   // waves 0, 1: 8 columns each
+  const size_t stepQ = (size_t)4 * ld;
+
+  auto issue = [&](int stage) {
+    double* Qs_ = smem + stage * STAGE + wave * kTile;
+#pragma unroll
+    for (int q = 0; q < BKs / 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pQ + q * stepQ),
+                                       (__attribute__((address_space(3))) void*)(Qs_ + 4 * q * kTile), 16, 0, 0);
+    if (wave < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pT,
+                                       (__attribute__((address_space(3))) void*)(smem + stage * STAGE + BKs * kTile +
+                                                                                 wave * 8 * TR),
+                                       16, 0, 0);
+    pQ += (BKs / 4) * stepQ;
+    pT += (size_t)BKs * ld;
+  };
+
+  // element offsets of this lane's fragments inside a stage for k-step 0 (k = l4); k-step kk adds 4 kk rows
+  const int sw = l4 & 1;
+  const int offA = l4 * kTile + ((rA ^ sw) << 4) + l15;
+  const int offB = l4 * kTile + ((rB ^ sw) << 4) + l15;
+  const int offT = BKs * kTile + l4 * TR + l15;
+  int offQ[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) offQ[s] = l4 * kTile + ((cbs[s] ^ sw) << 4) + l15;
+
+  double pfA[3], qfA[NS], pfB[3], qfB[NS];
+#define CCGP_DLOADF(PF, QF, STG, KK)                                                             \
+  do {                                                                                          \
+    const double* St_ = smem + (STG) * STAGE;                                                   \
+    PF[0] = St_[(KK) * 4 * kTile + offA];                                                       \
+    PF[1] = St_[(KK) * 4 * kTile + offB];                                                       \
+    PF[2] = St_[(KK) * 4 * TR + offT];                                                          \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) QF[s] = St_[(KK) * 4 * kTile + offQ[s]];     \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+#define CCGP_DMFMAS(PF, QF, S0, S1)                                                              \
+  do {                                                                                          \
+    _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                       \
+      const double pf = s >= 9 ? PF[2] : (s <= wave ? PF[0] : PF[1]);                           \
+      acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(QF[s], pf, acc[s], 0, 0, 0);                \
+    }                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+  constexpr int SH = 3;   // MFMAs before the next step's fragment loads are issued
+
+  const int nk = Kdim / BKs;
+  issue(0);
+  __syncthreads();
+  if (nk > 1) issue(1);
+  CCGP_DLOADF(pfA, qfA, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stg = kt & 1;
+    CCGP_DMFMAS(pfA, qfA, 0, SH);
+    CCGP_DLOADF(pfB, qfB, stg, 1);
+    CCGP_DMFMAS(pfA, qfA, SH, NS);
+    CCGP_DMFMAS(pfB, qfB, 0, SH);
+    CCGP_DLOADF(pfA, qfA, stg, 2);
+    CCGP_DMFMAS(pfB, qfB, SH, NS);
+    CCGP_DMFMAS(pfA, qfA, 0, SH);
+    CCGP_DLOADF(pfB, qfB, stg, 3);
+    CCGP_DMFMAS(pfA, qfA, SH, NS);
+    if (kt + 1 < nk) {
+      __syncthreads();
+      if (kt + 2 < nk) issue(stg);
+    }
+    CCGP_DMFMAS(pfB, qfB, 0, SH);
+    if (kt + 1 < nk) CCGP_DLOADF(pfA, qfA, stg ^ 1, 0);
+    CCGP_DMFMAS(pfB, qfB, SH, NS);
+  }
+#undef CCGP_DLOADF
+#undef CCGP_DMFMAS
+
+  // C -= acc: all loads of a group before its stores (see gemm_tile)
+#pragma unroll
+  for (int g0 = 0; g0 < NS; g0 += 4) {
+    double cv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = g0 + u;
+      if (s >= NS) break;
+      const int rb = s >= 9 ? 0 : (s <= wave ? rA : rB);
+      double* base = s >= 9 ? Ct : C;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[u][r] = base[rb * 16 + l15 + (size_t)(cbs[s] * 16 + l4 + 4 * r) * ld];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = g0 + u;
+      if (s >= NS) break;
+      const int rb = s >= 9 ? 0 : (s <= wave ? rA : rB);
+      double* base = s >= 9 ? Ct : C;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        base[rb * 16 + l15 + (size_t)(cbs[s] * 16 + l4 + 4 * r) * ld] = cv[u][r] - acc[s][r];
+    }
+  }
+}
+
 template <int S>
 constexpr size_t gemm_lds_bytes() {
   return sizeof(double) * 2 * TileGeom<S, false>::BK * (kTile + kTile / S);   // two unpadded stages
 }
 
+// Workgroups of one launch.  update (MODE 0), per matrix: ONE workgroup for the diagonal tile + right-hand
+// sides (diag_rhs_tile, never split into strips), then the tile rows below the diagonal and the extra
+// tile rows (prediction: r(x_t)'; inverse / gradient: identity), each as S column strips.  trsm (MODE 1):
+// tile rows j+1 .. nt-1, the thin right-hand-side tile row nt, then the extra rows.
+__host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, int ne, int S) {
+  return mode == 0 ? 1 + ((nt - 1 - j) + ne) * S : (nt - j) + ne;
+}
+
 template <int MODE, int S>
 __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
-  // tile rows j..nt+ne (update) / j+1..nt+ne (trsm); row nt is the thin right-hand-side tile,
-  // rows above nt are full tiles of extra rows (prediction: r(x_t)')
-  const int ntile = (MODE == 0 ? g.nt - g.j + 1 : g.nt - g.j) + g.ne;
   // block index -> (matrix, tile, strip): strips of a tile adjacent, tiles of a matrix on one
   // XCD group (blocks are dealt round-robin over the 8 XCDs, so index % 8 labels the group and
   // all tiles of one matrix share the Q panel in that XCD's L2)
   const int L = blockIdx.x;
-  const int per_grp = 8 * ntile * S;
+  const int per_grp = 8 * gemm_units_per_matrix(MODE, g.nt, g.j, g.ne, S);
   const int grp = L / per_grp, r = L % per_grp;
   const int b = grp * 8 + (r & 7);
-  const int t = (r >> 3) / S, strip = (r >> 3) % S;
   if (b >= g.nb) return;
-  const int i = g.j + t + (MODE == 0 ? 0 : 1);
-  const bool thin = i == g.nt;
   double* Ab = g.A + (size_t)b * g.a_stride;
   const int ld = g.ld;
+  int u = r >> 3;   // unit index inside the matrix
+  int i, strip = 0;
+  if (MODE == 0) {
+    if (u == 0) {
+      diag_rhs_tile(smem, Ab + (size_t)g.j * kTile, Ab + g.npad, ld, g.j * kTile,
+                    Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld);
+      return;
+    }
+    u -= 1;
+    strip = u % S;
+    i = g.j + 1 + u / S;
+    if (i >= g.nt) i += 1;   // the right-hand-side tile row nt went with the diagonal tile
+  } else {
+    i = g.j + 1 + u;
+  }
+  const bool thin = i == g.nt;
   const int c0 = strip * (kTile / S);   // first column of this strip inside the tile
 
   // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
@@ -282,8 +440,10 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   }
   double* C = Ab + (size_t)i * kTile + ((size_t)g.j * kTile + c0) * ld;
   constexpr bool TRI = MODE == 1 && S == 1;   // trsm: Q is the lower-triangular inverse block
-  if (thin) gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
-  else gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
+  if constexpr (MODE == 1) {
+    if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE); return; }
+  }
+  gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
 }
 
 // distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
@@ -294,42 +454,37 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   }
 CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2)
 CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
-CCGP_DEFINE_GEMM(chol_update_s4_kernel, 0, 4, 3)
+// trsm exists at S = 1 only: it is in place (reads the whole tile row, writes its own columns), so column
+// strips of one tile would race
 CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
-CCGP_DEFINE_GEMM(chol_trsm_s2_kernel, 1, 2, 2)
-CCGP_DEFINE_GEMM(chol_trsm_s4_kernel, 1, 4, 3)
 #undef CCGP_DEFINE_GEMM
 
-// Strip count for an update launch: minimise ceil(workgroups / resident slots) x time per
-// workgroup.  Slots per chip (2 / 3 / 3 workgroups per CU by LDS) and the relative per-flop
-// efficiency of the narrower strips (1 / 0.80 / 0.65) were fitted to per-launch rocprof
-// timings on MI355X (profiles/r01c_strip_selection.md); with the final round-1 kernels the selection is at
-// the per-launch optimum of the three pinned runs within noise (profiles/r01j_strip_table.md).
-static int pick_strips(int tiles) {
-  const int slots[3] = {512, 768, 768};
-  const double eff[3] = {1.0, 0.80, 0.65};
-  int best = 1;
-  double best_cost = 1e300;
-  for (int q = 0; q < 3; ++q) {
-    const int S = 1 << q;
-    const double cost = (double)((tiles * S + slots[q] - 1) / slots[q]) / (S * eff[q]);
-    if (cost < best_cost) { best_cost = cost; best = S; }
-  }
-  return best;
+// Strip count for an update launch.  Measured on MI355X with the round-2 kernels (rocprofv3 per-launch
+// tables, profiles/r02_update_schedule.md): the time of a launch is a step function of its workgroup
+// count in units of 256 (one workgroup per CU; the second workgroup of a CU shares its MFMA pipe, so
+// 256 more workgroups cost as much again):
+//   S = 1:  16.3 us x ceil(W1 / 256)               per 128-deep block of K,  W1 = nb (1 + tiles)
+//   S = 2:  13.7 us + 7.8 us x (ceil(W2 / 256) - 1)                          W2 = nb (1 + 2 tiles)
+// so two half-width strips win when W1 is just above a multiple of 256.  That holds while the launch is
+// small enough for the second read of the row panels to come from L2 / Infinity Cache; beyond ~2000
+// workgroups a strip costs 8.9 us instead of 7.8 and S = 1 always wins (whole 512-matrix chunks).
+// S = 4 never wins any more (the single-workgroup diagonal tile is its long pole) and is gone.
+static int pick_strips(int nb8, int tiles) {
+  const long w1 = (long)nb8 * (1 + tiles), w2 = (long)nb8 * (1 + 2 * tiles);
+  if (tiles == 0 || w1 > 2048) return 1;
+  const double c1 = 16.3 * (double)((w1 + 255) / 256);
+  const double c2 = 13.7 + 7.8 * (double)((w2 + 255) / 256 - 1);
+  return c2 < c1 ? 2 : 1;
 }
 
 static void launch_gemm(hipStream_t s, const GemmArgs& g, int mode, int S) {
-  const int ntile = (mode == 0 ? g.nt - g.j + 1 : g.nt - g.j) + g.ne;
   const int nb8 = round_up(g.nb, 8);
-  const dim3 grid(nb8 * ntile * S), block(256);
+  const dim3 grid(nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S)), block(256);
   if (mode == 0) {
     if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
-    else if (S == 2) hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
-    else hipLaunchKernelGGL(chol_update_s4_kernel, grid, block, gemm_lds_bytes<4>(), s, g);
+    else hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
   } else {
-    if (S == 1) hipLaunchKernelGGL(chol_trsm_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
-    else if (S == 2) hipLaunchKernelGGL(chol_trsm_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
-    else hipLaunchKernelGGL(chol_trsm_s4_kernel, grid, block, gemm_lds_bytes<4>(), s, g);
+    hipLaunchKernelGGL(chol_trsm_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
   }
 }
 
@@ -853,12 +1008,7 @@ struct GroupRun {
     dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;
-    static int env_s = -1;   // CCGP_STRIPS=1|2|4 pins the strip count (profiling only)
-    if (env_s < 0) {
-      const char* e = getenv("CCGP_STRIPS");
-      env_s = e ? atoi(e) : 0;
-    }
-    force_s = env_s;
+    force_s = h->opt_strips;   // ccgp_set_option(CCGP_OPT_UPDATE_STRIPS): 0 = pick_strips per launch
   }
 
   // T_ij = A_ij - sum_{k<j} L_ik L_jk' for every tile row of block column j (nothing to do at j = 0)
@@ -867,7 +1017,7 @@ struct GroupRun {
     ScopedTimer t(h, CCGP_T_UPDATE, s);
     g.j = j;
     g.mode = 0;
-    launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8) * (nt - j + 1 + w.ne)));
+    launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8), nt - 1 - j + w.ne));
   }
 
   // L_jj, W_j = L_jj^-1, then L_ij = T_ij W_j' for the rows below
@@ -881,7 +1031,7 @@ struct GroupRun {
       ScopedTimer t(h, CCGP_T_TRSM, s);
       g.j = j;
       g.mode = 1;
-      launch_gemm(s, g, 1, 1);   // trsm is in place: strips of one tile would race (read-all / write-own)
+      launch_gemm(s, g, 1, 1);
     }
   }
 
@@ -945,12 +1095,11 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
                     BlockedWs w, double* loglik, double* beta, int* status, const BlockedJob* job) {
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
-    const void* ks[] = {(const void*)chol_update_kernel, (const void*)chol_update_s2_kernel,
-                        (const void*)chol_update_s4_kernel, (const void*)chol_trsm_kernel,
-                        (const void*)chol_trsm_s2_kernel, (const void*)chol_trsm_s4_kernel,
-                        (const void*)rinv_tile_kernel<false>, (const void*)rinv_tile_kernel<true>};
-    for (const void* k : ks)
-      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
+    raise_lds_limit((const void*)chol_update_kernel, "chol_update_kernel");
+    raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
+    raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
+    raise_lds_limit((const void*)rinv_tile_kernel<false>, "rinv_tile_kernel<false>");
+    raise_lds_limit((const void*)rinv_tile_kernel<true>, "rinv_tile_kernel<true>");
   }
   GroupRun r{};
   r.h = h; r.s = h->stream; r.X = X; r.n = n; r.d = d; r.y = y; r.dv = dv; r.b0 = b0; r.nb = nb;

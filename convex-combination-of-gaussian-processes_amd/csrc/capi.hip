@@ -28,6 +28,22 @@ int fail(ccgp_handle* h, int code, const std::string& msg) {
   return code;
 }
 
+// after enqueueing kernels: launch errors, and a refused kernel-attribute request (raise_lds_limit)
+#define CCGP_LAUNCH_CHECK()                                                         \
+  do {                                                                              \
+    CCGP_HIP(hipGetLastError());                                                    \
+    if (!ccgp::attr_error().empty()) return fail(h, CCGP_EHIP, ccgp::attr_error()); \
+  } while (0)
+
+// the Matern / spline families exist for the 1-D scripts only
+int check_family(ccgp_handle* h, const KernelFamily& fam, int d, int K) {
+  if (fam.id != 0 && d != 1)
+    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
+  if (fam.id == 2 && K != 2)
+    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+  return CCGP_OK;
+}
+
 int ensure_ws(ccgp_handle* h, size_t bytes) {
   if (bytes <= h->ws_bytes) return CCGP_OK;
   if (h->ws) {
@@ -84,9 +100,18 @@ bool bad_shape(int n, int d, int K) {
 // blocked-path chunk size (matrices per pass) under the workspace limit
 int blocked_chunk(const ccgp_handle* h, int npad, int B, int ne = 0) {
   size_t per = blocked_ws_bytes(npad, 1, ne);
-  size_t nb = h->ws_limit / per;
+  // never plan beyond what the device can give right now (other handles / processes may share it):
+  // free memory plus what this handle would release by regrowing, less a margin
+  size_t limit = h->ws_limit, free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const size_t margin = size_t(1) << 30;
+    const size_t avail = free_b + h->ws_bytes > margin ? free_b + h->ws_bytes - margin : 0;
+    if (avail < limit) limit = avail;
+  }
+  size_t nb = limit / per;
   if (nb < 1) nb = 1;
   if (nb > (size_t)B) nb = B;
+  if (nb > 65535) nb = 65535;   // the chunk index is a grid y / z dimension in cov_kernel, rhs_rows_kernel, ...
   return (int)nb;
 }
 
@@ -100,11 +125,8 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
   if (B == 0) return CCGP_OK;
   DrawView dv{dparams, B, K, d};
   dv.fam = h->fam;
-  if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-  if (dv.fam.id == 2 && K != 2)
-    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
-  static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
+  if (int frc = check_family(h, dv.fam, d, K)) return frc;
+  const bool force_lds = h->opt_small_lds != 0;   // ccgp_set_option(CCGP_OPT_SMALL_LDS): A/B switch for measurements
   // the fused evaluators generate Gaussian correlations in registers; any other family goes through
   // the materialised-matrix (blocked) path, where only cov_kernel knows about families
   const bool gauss = dv.fam.id == 0;
@@ -118,7 +140,7 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
     else
       launch_small_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
                           d_status);
-    CCGP_HIP(hipGetLastError());
+    CCGP_LAUNCH_CHECK();
     return CCGP_OK;
   }
   const int npad = round_up(n, kTile);
@@ -132,7 +154,7 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
     blocked_loglik(h, dX, n, d, dy, dv, b0, nb, npad, sigma2, mean_mode, tau2, w, d_loglik, d_beta,
                    d_status);
   }
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   return CCGP_OK;
 }
 
@@ -257,6 +279,10 @@ int ccgp_create(int device, ccgp_handle** out) {
     return CCGP_EHIP;
   }
   h->stream = h->own_stream;
+  // default scratch cap: three quarters of the device (216 of 288 GB on MI355X -- the whole 512-point
+  // n = 4096 grid of BASELINE config 4 is 73 GB and runs as ONE chunk)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) h->ws_limit = total_b / 4 * 3;
   *out = h;
   return CCGP_OK;
 }
@@ -302,6 +328,19 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes) {
   if (!h || bytes < (size_t(1) << 20)) return CCGP_EINVAL;
   h->ws_limit = bytes;
   return CCGP_OK;
+}
+
+int ccgp_set_option(ccgp_handle* h, int option, int value) {
+  if (!h) return CCGP_EINVAL;
+  if (option == CCGP_OPT_UPDATE_STRIPS && (value == 0 || value == 1 || value == 2)) {
+    h->opt_strips = value;
+    return CCGP_OK;
+  }
+  if (option == CCGP_OPT_SMALL_LDS && (value == 0 || value == 1)) {
+    h->opt_small_lds = value;
+    return CCGP_OK;
+  }
+  return fail(h, CCGP_EINVAL, "ccgp_set_option: unknown option or value");
 }
 
 int ccgp_synchronize(ccgp_handle* h) {
@@ -374,15 +413,12 @@ static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* 
   CCGP_HIP(hipMemcpyAsync(dp, params_row, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
   DrawView dv{dp, 1, K, d};
   dv.fam = h->fam;
-  if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-  if (dv.fam.id == 2 && K != 2)
-    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+  if (int frc = check_family(h, dv.fam, d, K)) return frc;
   {
     ScopedTimer t(h, CCGP_T_COV);
     launch_cov_dense(h->stream, gram ? dX : dXn, m, dX, n, d, dv, 0, dout, m);
   }
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   CCGP_HIP(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToHost, h->stream));
   CCGP_HIP(hipStreamSynchronize(h->stream));
   return CCGP_OK;
@@ -433,7 +469,7 @@ static int rinv_terms(ccgp_handle* h, const double* R_inv, const double* y, int 
   CCGP_HIP(hipMemcpyAsync(dR, R_inv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
   CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(rinv_terms_kernel, dim3(1), dim3(256), 0, h->stream, dR, dy, n, beta, dmf, dcs, dsc);
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   if (mean_factor) CCGP_HIP(hipMemcpyAsync(mean_factor, dmf, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   if (colsum) CCGP_HIP(hipMemcpyAsync(colsum, dcs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   CCGP_HIP(hipMemcpyAsync(scal, dsc, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
@@ -494,7 +530,7 @@ int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, dou
   CCGP_HIP(hipMemcpyAsync(dv1, var_factor1, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(predict_factors_kernel, dim3(m), dim3(256), 0, h->stream, dr, m, n, beta, dmf,
                      dv1, var_factor2, dR, sigma2, dmean, dvar);
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   CCGP_HIP(hipMemcpyAsync(out_mean, dmean, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
   CCGP_HIP(hipMemcpyAsync(out_var, dvar, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
   CCGP_HIP(hipStreamSynchronize(h->stream));
@@ -586,10 +622,7 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
     CCGP_HIP(hipMemsetAsync(dst, 0, sizeof(int) * (size_t)B, h->stream));
     DrawView dv{dp, B, K, d};
     dv.fam = h->fam;
-    if (dv.fam.id != 0 && d != 1)
-      return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-    if (dv.fam.id == 2 && K != 2)
-      return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+    if (int frc = check_family(h, dv.fam, d, K)) return frc;
     Carver tail(static_cast<char*>(h->ws) + Carver::al(blocked_ws_bytes(npad, nbc, ne)));
     BlockedJob job{};
     job.kind = kJobGrad; job.grad = dg; job.Btot = B;
@@ -601,7 +634,7 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
       blocked_loglik(h, dX, n, d, dy, dv, b0, nb, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, dll, dbeta,
                      dst, &job);
     }
-    CCGP_HIP(hipGetLastError());
+    CCGP_LAUNCH_CHECK();
     std::vector<int> st(B);
     if (out_loglik) CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
     if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
@@ -631,15 +664,12 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
   DrawView dv{dp, B, K, d};
   dv.fam = h->fam;
-  if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-  if (dv.fam.id == 2 && K != 2)
-    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+  if (int frc = check_family(h, dv.fam, d, K)) return frc;
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     launch_small_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst, dgp);
   }
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   std::vector<int> st(B);
   if (out_loglik) CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
   if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
@@ -717,15 +747,12 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     CCGP_HIP(hipMemsetAsync(dst, 0, sizeof(int), h->stream));
     DrawView dv{dp, 1, K, d};
     dv.fam = h->fam;
-    if (dv.fam.id != 0 && d != 1)
-      return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-    if (dv.fam.id == 2 && K != 2)
-      return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+    if (int frc = check_family(h, dv.fam, d, K)) return frc;
     BlockedJob job{};
     job.kind = kJobInverse; job.Rinv = dR;
     BlockedWs w = blocked_carve(h->ws, npad, 1, nt);
     blocked_loglik(h, dX, n, d, dy, dv, 0, 1, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, dll, dbt, dst, &job);
-    CCGP_HIP(hipGetLastError());
+    CCGP_LAUNCH_CHECK();
     CCGP_HIP(hipMemcpyAsync(out_Rinv, dR, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
     CCGP_HIP(hipStreamSynchronize(h->stream));
   } else if (out_Rinv) {
@@ -742,15 +769,12 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     CCGP_HIP(hipMemcpyAsync(dp, row.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     DrawView dv{dp, 1, K, d};
     dv.fam = h->fam;
-    if (dv.fam.id != 0 && d != 1)
-      return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-    if (dv.fam.id == 2 && K != 2)
-      return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+    if (int frc = check_family(h, dv.fam, d, K)) return frc;
     {
       ScopedTimer t(h, CCGP_T_FUSED);
       launch_small_inverse(h->stream, dX, n, d, dv, 0, dR, dst);
     }
-    CCGP_HIP(hipGetLastError());
+    CCGP_LAUNCH_CHECK();
     CCGP_HIP(hipMemcpyAsync(out_Rinv, dR, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
     CCGP_HIP(hipStreamSynchronize(h->stream));
   }
@@ -786,15 +810,12 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
   CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
   DrawView dv{dp, 1, K, d};
   dv.fam = h->fam;
-  if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-  if (dv.fam.id == 2 && K != 2)
-    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+  if (int frc = check_family(h, dv.fam, d, K)) return frc;
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     launch_small_reg_logdet_designs(h->stream, dXs, n, d, dv, B, dld, dst);
   }
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   std::vector<int> st(B);
   CCGP_HIP(hipMemcpyAsync(out_logdet, dld, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
   CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
@@ -885,7 +906,7 @@ int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const doub
                   dbeta, dst);
   if (rc) return rc;
   hipLaunchKernelGGL(row_logmeanexp_kernel, dim3(G), dim3(256), 0, h->stream, dll, N, take_log, dout);
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   CCGP_HIP(hipMemcpyAsync(out, dout, sizeof(double) * G, hipMemcpyDeviceToHost, h->stream));
   if (out_logs) CCGP_HIP(hipMemcpyAsync(out_logs, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
   std::vector<int> st(B);
@@ -912,10 +933,7 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   CCGP_HIP(hipSetDevice(h->device));
   DrawView dv{dparams, S, K, d};
   dv.fam = h->fam;
-  if (dv.fam.id != 0 && d != 1)
-    return fail(h, CCGP_EUNSUPPORTED, "the Matern / spline families are one-dimensional (D1:348-389): d must be 1");
-  if (dv.fam.id == 2 && K != 2)
-    return fail(h, CCGP_EUNSUPPORTED, "CCGP_KERNEL_MATERN_SPLINE is the two-family script's pair (D1F:453-462): K must be 2");
+  if (int frc = check_family(h, dv.fam, d, K)) return frc;
   if (dv.fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
     // blocked path: the m cross-correlation rows ride along as extra tile rows of the sweep
     const int npad = round_up(n, kTile), ne = (m + kTile - 1) / kTile;
@@ -937,12 +955,12 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
       blocked_loglik(h, dX, n, d, dy, dv, b0, nb, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, ll, bt, st,
                      &pr);
     }
-    CCGP_HIP(hipGetLastError());
+    CCGP_LAUNCH_CHECK();
     return CCGP_OK;
   }
   {
     ScopedTimer t(h, CCGP_T_FUSED);
-    static const bool force_lds = getenv("CCGP_SMALL_LDS") != nullptr;   // A/B switch for measurements
+    const bool force_lds = h->opt_small_lds != 0;
     if (small_reg_supported(n, d, false, true) && !force_lds)
       launch_small_reg_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
                                d_status);
@@ -950,7 +968,7 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
       launch_small_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
                            d_status);
   }
-  CCGP_HIP(hipGetLastError());
+  CCGP_LAUNCH_CHECK();
   return CCGP_OK;
 }
 

@@ -38,7 +38,9 @@ struct ccgp_handle {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  size_t ws_limit = size_t(24) << 30;
+  size_t ws_limit = size_t(24) << 30;   // ccgp_create replaces this by 3/4 of the device's memory
+  int opt_strips = 0;                   // CCGP_OPT_UPDATE_STRIPS
+  int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
   // grow-only device scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;
@@ -248,6 +250,20 @@ __device__ __forceinline__ double corr_of_dist(const KernelFamily& f, double dis
   if (f.id == 0) return exp_cov(-dist);
   if (f.id == 2 && component == 1) return spline_corr(dist);
   return matern_corr(f, dist);
+}
+
+// Raise a kernel's dynamic-LDS ceiling to the 160 KiB of a gfx950 CU.  A refusal is remembered (first
+// one wins) and reported by the next C-ABI call's launch check instead of surfacing later as an opaque
+// launch failure.
+inline std::string& attr_error() {
+  static std::string e;
+  return e;
+}
+inline void raise_lds_limit(const void* kernel, const char* name) {
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
+  if (e != hipSuccess && attr_error().empty())
+    attr_error() = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for ") + name + ": " +
+                   hipGetErrorString(e);
 }
 
 struct ScopedTimer {

@@ -6,9 +6,11 @@
 //   dist_c(i,j) = (u_ci + u_cj) - 2 sum_k (x_ik theta_ck) x_jk,   u_ci = sum_k theta_ck x_ik^2
 // (HX:352-355), so the diagonal is exp(-rounding) exactly as in R, not a forced 1.
 //
-// Roofline: HBM-bound on the output write when the matrix is materialised
-// (8 n^2 B dense, 4 n^2 B lower tiles) -- X (n x d) is read once per tile into LDS and
-// every output column is written as 512 B contiguous per wave (lane = row).
+// Roofline: the algorithmic traffic is the output write (8 n^2 B dense, 4 n^2 B lower tiles; X is read
+// once per tile into LDS and every output column is written as 512 B contiguous per wave, lane = row),
+// but the kernel is fp64-VALU bound, not HBM-bound: K (d + ~22) fp64 instructions per entry (distance,
+// exp_cov, mix).  Measured at n = 4096, d = 5, K = 3: 2.2 TB/s of lower-tile writes = 0.27 of the HBM
+// peak with the CUs 97 % busy (profiles/r01j).
 #include "ccgp_internal.h"
 
 namespace ccgp {
@@ -140,6 +142,15 @@ size_t cov_lds(int d, int K) {
   return sizeof(double) * (size_t)(2 * d * 64 + 2 * K * 64 + K * d + K);
 }
 
+// d = 64, K = 8 needs 78 KiB: above the 64 KiB a kernel gets without asking
+void cov_prepare() {
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask)) {
+    raise_lds_limit((const void*)cov_kernel<0>, "cov_kernel<0>");
+    raise_lds_limit((const void*)cov_kernel<1>, "cov_kernel<1>");
+  }
+}
+
 }  // namespace
 
 void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, int n, int d,
@@ -149,6 +160,7 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = draw;
   a.out = out; a.batch_stride = 0; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
   a.raw_mix = dv.fam.id == 2 && A != Bm;   // the two-family script's corr.vec.combined never divides (D1F:479)
+  cov_prepare();
   dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, 1);
   if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
   else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
@@ -162,6 +174,7 @@ void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv,
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
   a.out = Abase; a.batch_stride = batch_stride; a.ldo = ld; a.mode = mean_mode;
   a.sigma2 = sigma2; a.tau2 = tau2; a.lower_tiles = 1; a.npad = npad;
+  cov_prepare();
   int nt64 = npad / 64;
   dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
   if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
@@ -177,6 +190,7 @@ void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const d
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
   a.out = Abase; a.batch_stride = batch_stride; a.ldo = ldo; a.mode = 0; a.lower_tiles = 0; a.npad = 0;
   a.raw_mix = dv.fam.id == 2;
+  cov_prepare();
   dim3 grid((m + kCovRows - 1) / kCovRows, (n + kCovCols - 1) / kCovCols, nb);
   if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
   else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);

@@ -320,8 +320,7 @@ static void small_launch(hipStream_t s, const SmallArgs& a, int ndraws, int nchu
   size_t lds = small_lds_bytes(a.n, a.d, a.kind == kRowsLoglik ? 0 : a.mtile);
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
-    (void)hipFuncSetAttribute((const void*)small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kLdsBytes - 64);
+    raise_lds_limit((const void*)small_kernel, "small_kernel");
   }
   hipLaunchKernelGGL(small_kernel, dim3(ndraws, nchunks), dim3(256), lds, s, a);
 }

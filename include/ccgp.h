@@ -89,8 +89,15 @@ int ccgp_set_stream(ccgp_handle* h, void* hip_stream);
  *                     predict.post D1F:737-754 (ccgp_predict_batch) uses that same vector. */
 enum { CCGP_KERNEL_GAUSS = 0, CCGP_KERNEL_MATERN = 1, CCGP_KERNEL_MATERN_SPLINE = 2 };
 int ccgp_set_kernel(ccgp_handle* h, int family, double nu);
-/* cap on device scratch used per launch group (default 24 GiB); batches are chunked */
+/* cap on device scratch used per launch group; larger batches are processed in chunks.  Default: three
+ * quarters of the device's memory (216 of 288 GB on MI355X), and never more than is free at call time. */
 int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
+/* measurement switches (A/B runs under rocprof; results do not depend on them):
+ *   CCGP_OPT_UPDATE_STRIPS  0 = choose per launch (default), 1 | 2 = pin the column-strip count of the
+ *                           blocked Cholesky's trailing-update launches
+ *   CCGP_OPT_SMALL_LDS      1 = run n <= 128 on the in-LDS evaluator instead of the register-resident one */
+enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1 };
+int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);
 int ccgp_synchronize(ccgp_handle* h);

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_ground_vibrations_fit_reproduces_the_recorded_run_statistically(handle):
+    # (the per-test-point comparison with the recorded table is tests/test_reference_pins_gpu.py)
     from ccgp_amd import fit
     from ccgp_amd.rsurface import CombinedGP
     D, y, Dt, yt = load_gv(50)

@@ -159,16 +159,50 @@ def pmc_traffic(kernel, matrices_per_launch):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2, budget_s=20.0):
-    """The oracle (numpy restatement of the reference's R operation sequence: materialised
-    U + t(U) + V temporaries, LU inverse via solve(), then dmnorm's chol + chol2inv) timed on
-    this host's cores.  kind = "port": R itself is not installed anywhere in this pipeline."""
-    from oracle import ccgp_oracle as orc
+def cpu_model():
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
     except Exception:
-        threads = os.cpu_count() or 1
+        pass
+    return "unknown"
+
+
+def cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core, one_core_evals):
+    """SURVEY 8(d)'s CPU baseline: the compiled evaluator of oracle/cpu_baseline (covariance build, LAPACK dpotrf,
+    two dtrsv, log-likelihood: the same algorithmic work as the GPU path), OpenMP over evaluations with one
+    evaluation per core, on every core of this host and on one core.  Bounded sample of the workload's draws."""
+    from oracle.cpu_baseline import loader as cpu
+    cores = cpu.max_threads()
+    B = min(P.shape[0], per_core * cores)
+    # warm-up: the first second of a fresh OpenMP team runs several times slower (thread start, core wake-up)
+    t0 = time.perf_counter()
+    cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
+    if time.perf_counter() - t0 < 1.0:
+        while time.perf_counter() - t0 < 1.0:
+            cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
+    t0 = time.perf_counter()
+    cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
+    t_all = time.perf_counter() - t0
+    b1 = min(P.shape[0], one_core_evals)
+    t0 = time.perf_counter()
+    cpu.loglik_batch(X, y, K, P[:b1], sigma2, mode, tau2, threads=1)
+    t_one = time.perf_counter() - t0
+    return {"all_cores": B / t_all, "one_core": b1 / t_one, "cores": cores, "unit": "evals/s",
+            "sample": "%d evaluations on %d cores in %.2f s, %d on one core in %.2f s" % (B, cores, t_all, b1, t_one),
+            "lapack": ("built-in C Cholesky (n <= 128: concurrent tiny LAPACK calls serialise inside OpenBLAS)"
+                       if X.shape[0] <= 128 else
+                       "scipy OpenBLAS dpotrf/dtrsv, single-threaded per evaluation" if cpu.lapack_bound()
+                       else "built-in C Cholesky (no LAPACK found)")}
+
+
+def cpu_reference_opcount(workload, X, y, P, K, sigma2, mode, tau2, budget_s=8.0):
+    """The oracle (numpy restatement of the reference's R operation sequence: materialised U + t(U) + V
+    temporaries, LU inverse via solve(), then dmnorm's chol + chol2inv) timed with numpy's BLAS threads: an
+    emulation of what R + LAPACK would do per evaluation, not a measurement of R (R is not installed anywhere)."""
+    from oracle import ccgp_oracle as orc
     d = X.shape[1]
     done, t0 = 0, time.perf_counter()
     while True:
@@ -176,11 +210,46 @@ def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2, budget_s=20.0):
         orc.loglik_general(X, y, w, Th, sigma2, mode, tau2)
         done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 1000000:
+        if el > budget_s or done >= 100000:
             break
-    return {"value": done / el, "unit": "evals/s", "cores": int(threads), "kind": "port",
-            "sample": "%d evaluations of the %s workload (n=%d) through oracle.loglik_general, %.1f s"
-                      % (done, workload, X.shape[0], el)}
+    return {"value": done / el, "unit": "evals/s", "sample": "%d evaluations of %s through oracle.loglik_general in %.1f s"
+                                                              % (done, workload, el)}
+
+
+def cpu_predict_sample(sets, P5, draws_per_core=8):
+    """cfg5 on the CPU: the compiled evaluator's predict.post tables for a bounded number of draws of every set."""
+    from oracle.cpu_baseline import loader as cpu
+    cores = cpu.max_threads()
+    S = min(P5.shape[0], draws_per_core * cores)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:                 # warm-up of the OpenMP team (see cpu_compiled_loglik)
+        cpu.predict_batch(sets[0][0], sets[0][1], 2, P5[:S], sets[0][2], 1.0, threads=cores)
+    pairs, t_all = 0, 0.0
+    for (Xs, ys, Xt) in sets:
+        t0 = time.perf_counter()
+        cpu.predict_batch(Xs, ys, 2, P5[:S], Xt, 1.0, threads=cores)
+        t_all += time.perf_counter() - t0
+        pairs += S * Xt.shape[0]
+    Xs, ys, Xt = sets[0]
+    s1 = min(S, 8)
+    t0 = time.perf_counter()
+    cpu.predict_batch(Xs, ys, 2, P5[:s1], Xt, 1.0, threads=1)
+    t_one = time.perf_counter() - t0
+    return {"all_cores": pairs / t_all, "one_core": s1 * Xt.shape[0] / t_one, "cores": cores,
+            "unit": "(draw, test point) predictions/s",
+            "sample": "%d draws x 17 sets on %d cores in %.2f s; %d draws of set 1 on one core in %.2f s" % (S, cores, t_all, s1, t_one)}
+
+
+def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2):
+    big = X.shape[0] > 1000
+    c = cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core=2 if big else 2000, one_core_evals=2 if big else 4000)
+    ref = cpu_reference_opcount(workload, X, y, P, K, sigma2, mode, tau2)
+    return {"value": c["all_cores"], "unit": "evals/s", "cores": c["cores"], "kind": "port",
+            "sample": "%s workload (n=%d): %s" % (workload, X.shape[0], c["sample"]),
+            "all_cores": c["all_cores"], "one_core": c["one_core"], "model": cpu_model(), "lapack": c["lapack"],
+            "what": "compiled evaluator oracle/cpu_baseline (covariance build + dpotrf + 2 dtrsv per evaluation, OpenMP "
+                    "over evaluations, one evaluation per core)",
+            "reference_opcount": ref}
 
 
 # ----------------------------------------------------------------------------- main
@@ -265,6 +334,19 @@ def main():
     gdev = dict(dtype=torch.float64, device="cpu" if host_gather else dev)
     gather_buf = [torch.empty(max(sizes), **gdev) for _ in range(world)] if world > 1 else None
     send_buf = torch.zeros(max(sizes), **gdev) if world > 1 else None
+
+    # CPU legs first (rank 0, N = 1 only), so that the GPU legs that follow are one contiguous stretch of device work
+    cpu_main, cpu_sec, sec_in = None, {}, None
+    if rank == 0 and world == 1 and args.workload == "cfg4" and not args.no_secondary:
+        sec_in = {"cfg2": cfg2_inputs(), "cfg3": cfg3_inputs(), "cfg5": cfg5_inputs()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_main = cpu_baseline(args.workload, X, y, P, K, sigma2, mode, tau2)
+        if sec_in is not None:
+            X2, y2, P2, K2, s22 = sec_in["cfg2"]
+            cpu_sec["cfg2"] = cpu_compiled_loglik(X2, y2, P2, K2, s22, api.MEAN_ZERO_PLUS_TAU2, 2500.0, 2000, 4000)
+            X3, y3, P3, K3, s23 = sec_in["cfg3"]
+            cpu_sec["cfg3"] = cpu_compiled_loglik(X3, y3, P3, K3, s23, api.MEAN_ZERO_PLUS_TAU2, 1e4, 800, 2000)
+            cpu_sec["cfg5"] = cpu_predict_sample(*sec_in["cfg5"])
 
     h = api.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -358,11 +440,11 @@ def main():
                                          "n^3/3 flop per evaluation is priced against the fp64 peak, which is the same "
                                          "78.6 TFLOP/s for vector and matrix instructions on this chip; see DESIGN.md)",
                                "launches": fl, "avg_launch_ms": fused_ms / max(fl, 1)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, X, y, P, K, sigma2, mode, tau2)
-        if world == 1 and args.workload == "cfg4" and not args.no_secondary:
+        if cpu_main is not None:
+            out["cpu_baseline"] = cpu_main
+        if sec_in is not None:
             # secondary line item: the Heat-Exchanger grid (BASELINE config 2) on the same GPU
-            X2, y2, P2, K2, s22 = cfg2_inputs()
+            X2, y2, P2, K2, s22 = sec_in["cfg2"]
             dX2 = torch.tensor(np.asfortranarray(X2).ravel(order="F"), **f64)
             dy2 = torch.tensor(y2, **f64)
             dP2 = torch.tensor(np.asfortranarray(P2).ravel(order="F"), **f64)
@@ -380,7 +462,7 @@ def main():
                                  "value": B2 / el2, "unit": "evals/s", "ms_per_pass": 1e3 * el2,
                                  "failed_evals": int((o3 != 0).sum().item())}]
             # config 3: 2-D anisotropic grid on maximin-100 (60 x 1728 evaluations at n = 100)
-            X3, y3, P3, K3, s23 = cfg3_inputs()
+            X3, y3, P3, K3, s23 = sec_in["cfg3"]
             dX3 = torch.tensor(np.asfortranarray(X3).ravel(order="F"), **f64)
             dy3 = torch.tensor(y3, **f64)
             dP3 = torch.tensor(np.asfortranarray(P3).ravel(order="F"), **f64)
@@ -398,7 +480,7 @@ def main():
                                      "value": B3 / el3, "unit": "evals/s", "ms_per_pass": 1e3 * el3,
                                      "failed_evals": int((q3 != 0).sum().item())})
             # config 5: Ground-Vibrations predictive mean/variance tables, all 17 train/test pairs
-            sets, P5 = cfg5_inputs()
+            sets, P5 = sec_in["cfg5"]
             S5 = P5.shape[0]
             dP5 = torch.tensor(np.asfortranarray(P5).ravel(order="F"), **f64)
             dsets, pairs = [], 0
@@ -421,6 +503,8 @@ def main():
                                      "value": pairs / el5, "unit": "(draw, test point) predictions/s",
                                      "ms_per_pass": 1e3 * el5,
                                      "failed_draws": int(sum(int((t[8] != 0).sum().item()) for t in dsets))})
+            for entry, key in zip(out["secondary"], ("cfg2", "cfg3", "cfg5")):
+                entry["cpu"] = cpu_sec.get(key)
         print(json.dumps(out))
     h.close()
     if world > 1:

@@ -332,8 +332,6 @@ def main():
     if args.workload == "cfg2":
         sizes = [1000 * s for s in shard.shard_sizes(total // 1000, world)]
     gdev = dict(dtype=torch.float64, device="cpu" if host_gather else dev)
-    gather_buf = [torch.empty(max(sizes), **gdev) for _ in range(world)] if world > 1 else None
-    send_buf = torch.zeros(max(sizes), **gdev) if world > 1 else None
 
     # CPU legs first (rank 0, N = 1 only), so that the GPU legs that follow are one contiguous stretch of device work
     cpu_main, cpu_sec, sec_in = None, {}, None
@@ -356,11 +354,14 @@ def main():
         h.set_workspace_limit(int(args.ws_limit_gib * 2 ** 30))
     h.reserve(n, d, K, max(B, 1), 0)
 
+    gathered = [None]
+
     def step():
         h.loglik_batch_dev(dX, n, d, dy, K, dP, B, sigma2, mode, tau2, d_ll, d_beta, d_st)
         if world > 1:
-            send_buf[:B] = d_ll                            # (gloo rehearsal: device -> host copy, synchronises)
-            dist.all_gather(gather_buf, send_buf)          # the one collective of the path
+            # the one collective of the path (shard.all_gather_rows: RCCL all-gather of the per-rank slices; in the
+            # gloo rehearsal the slice goes through host memory, which synchronises)
+            gathered[0] = shard.all_gather_rows(d_ll.cpu() if host_gather else d_ll, total)
 
     def fence():
         torch.cuda.synchronize()
@@ -393,7 +394,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank now holds every shard's log-likelihoods: check the gather against the local slice
-        full = torch.cat([g[:sz] for g, sz in zip(gather_buf, sizes)])
+        full = gathered[0]
         assert full.shape[0] == total and torch.equal(full[lo:hi].to(dev), d_ll), "all-gather mismatch"
     bad = int((d_st != 0).sum().item())
     finite = bool(torch.isfinite(d_ll).all().item())

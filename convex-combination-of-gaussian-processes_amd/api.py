@@ -63,6 +63,18 @@ SIGNATURES = {
     "ccgp_factors": (c_int, [c_void_p, _dp, c_double, _dp, c_int, _dp]),
     "ccgp_predict_from_factors": (c_int, [c_void_p, _dp, c_int, c_int, c_double, _dp, _dp, c_double,
                                           _dp, c_double, _dp, _dp]),
+    "ccgp_multi_create": (c_int, [c_int, _ip, POINTER(c_void_p)]),
+    "ccgp_multi_destroy": (c_int, [c_void_p]),
+    "ccgp_multi_count": (c_int, [c_void_p]),
+    "ccgp_multi_handle": (c_void_p, [c_void_p, c_int]),
+    "ccgp_multi_last_error": (c_char_p, [c_void_p]),
+    "ccgp_multi_set_kernel": (c_int, [c_void_p, c_int, c_double]),
+    "ccgp_multi_loglik_batch": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_int, _dp, c_int, c_double,
+                                        c_int, c_double, _dp, _dp, _ip]),
+    "ccgp_multi_grid_marginal": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_double, _dp, c_int, c_int,
+                                         c_double, c_int, c_double, _dp, _ip, _dp]),
+    "ccgp_multi_predict_batch": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_int, _dp, c_int, _dp, c_int,
+                                         c_double, _dp, _dp, _dp, _ip]),
     "ccgp_enable_timing": (c_int, [c_void_p, c_int]),
     "ccgp_get_timing": (c_int, [c_void_p, c_int, _dp, _ip]),
 }
@@ -118,6 +130,97 @@ def qigamma(p, alpha, beta):
     if rc:
         raise CcgpError(rc, "ccgp_qigamma")
     return out
+
+
+class MultiHandle:
+    """Several devices behind one host process (ccgp_multi_*): the batched calls are cut into contiguous shards,
+    one per listed device, and gathered in host memory.  devices: a count (0 .. k-1) or an explicit list; a device
+    may be listed more than once (the shards then share it)."""
+
+    def __init__(self, devices):
+        devs = list(range(devices)) if isinstance(devices, int) else [int(v) for v in devices]
+        arr = (c_int * len(devs))(*devs)
+        self._m = c_void_p()
+        rc = lib().ccgp_multi_create(len(devs), arr, ctypes.byref(self._m))
+        if rc:
+            self._m = None
+            raise CcgpError(rc, "ccgp_multi_create(%s) failed -- is every device visible?" % devs)
+        self.devices = devs
+
+    def close(self):
+        if getattr(self, "_m", None):
+            lib().ccgp_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise CcgpError(rc, lib().ccgp_multi_last_error(self._m).decode())
+        return rc
+
+    def count(self):
+        return lib().ccgp_multi_count(self._m)
+
+    def set_kernel(self, family=0, nu=0.0):
+        self._chk(lib().ccgp_multi_set_kernel(self._m, int(family), float(nu)))
+
+    def set_workspace_limit(self, nbytes):
+        for i in range(self.count()):
+            rc = lib().ccgp_set_workspace_limit(c_void_p(lib().ccgp_multi_handle(self._m, i)), int(nbytes))
+            if rc:
+                raise CcgpError(rc, "ccgp_set_workspace_limit")
+
+    def loglik_batch(self, X, y, K, params, sigma2, mean_mode=MEAN_PROFILE_BETA, tau2=0.0):
+        X, y = _f(X), _f(np.ravel(y))
+        n, d = X.shape
+        params = _f(np.atleast_2d(params))
+        B, P = params.shape
+        if P != K + K * d:
+            raise ValueError("params must have K + K*d = %d columns" % (K + K * d))
+        ll, beta = np.empty(B), np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        self._chk(lib().ccgp_multi_loglik_batch(self._m, _p(X), n, d, _p(y), K, _p(params), B, float(sigma2),
+                                                int(mean_mode), float(tau2), _p(ll), _p(beta), _ipt(st)))
+        return ll, beta, st
+
+    def grid_marginal(self, X, y, sigma2, hyper, N, tau, take_log, aniso_lambda=-1.0, want_logs=False):
+        X, y = _f(X), _f(np.ravel(y))
+        n, d = X.shape
+        hyper = _f(hyper)
+        G = hyper.shape[0]
+        out = np.empty(G)
+        arg = c_int()
+        logs = np.empty((G, N), dtype=np.float64) if want_logs else None
+        self._chk(lib().ccgp_multi_grid_marginal(self._m, _p(X), n, d, _p(y), float(sigma2), _p(hyper), G, int(N),
+                                                 float(tau), 1 if take_log else 0, float(aniso_lambda), _p(out),
+                                                 ctypes.byref(arg), _p(logs)))
+        return (out, arg.value, logs) if want_logs else (out, arg.value)
+
+    def predict_batch(self, X, y, K, params, Xtest, sigma2):
+        X, y = _f(X), _f(np.ravel(y))
+        n, d = X.shape
+        params = _f(np.atleast_2d(params))
+        S = params.shape[0]
+        Xtest = _f(np.atleast_2d(Xtest))
+        m = Xtest.shape[0]
+        mean = np.empty((S, m), dtype=np.float64, order="F")
+        var = np.empty((S, m), dtype=np.float64, order="F")
+        beta = np.empty(S)
+        st = np.zeros(S, dtype=np.int32)
+        self._chk(lib().ccgp_multi_predict_batch(self._m, _p(X), n, d, _p(y), K, _p(params), S, _p(Xtest), m,
+                                                 float(sigma2), _p(mean), _p(var), _p(beta), _ipt(st)))
+        return mean, var, beta, st
 
 
 class Handle:

@@ -1094,13 +1094,13 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
                     BlockedWs w, double* loglik, double* beta, int* status, const BlockedJob* job) {
   static unsigned long long attr_mask = 0;
-  if (first_use_on_device(attr_mask)) {
+  once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)chol_update_kernel, "chol_update_kernel");
     raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
     raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
     raise_lds_limit((const void*)rinv_tile_kernel<false>, "rinv_tile_kernel<false>");
     raise_lds_limit((const void*)rinv_tile_kernel<true>, "rinv_tile_kernel<true>");
-  }
+  });
   GroupRun r{};
   r.h = h; r.s = h->stream; r.X = X; r.n = n; r.d = d; r.y = y; r.dv = dv; r.b0 = b0; r.nb = nb;
   r.npad = npad; r.sigma2 = sigma2; r.mean_mode = mean_mode; r.tau2 = tau2; r.w = w;

@@ -144,8 +144,12 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
     return CCGP_OK;
   }
   const int npad = round_up(n, kTile);
-  const int nbc = blocked_chunk(h, npad, B);
+  int nbc = blocked_chunk(h, npad, B);
   int rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, 0));
+  while (rc == CCGP_ENOMEM && nbc > 1) {   // another handle / process took the memory in between: smaller chunks
+    nbc = (nbc + 1) / 2;
+    rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, 0));
+  }
   if (rc) return rc;
   CCGP_HIP(hipMemsetAsync(d_status, 0, sizeof(int) * (size_t)B, h->stream));
   for (int b0 = 0; b0 < B; b0 += nbc) {
@@ -316,8 +320,8 @@ int ccgp_set_kernel(ccgp_handle* h, int family, double nu) {
     h->fam = ccgp::KernelFamily{};
     return CCGP_OK;
   }
-  if ((family != CCGP_KERNEL_MATERN && family != CCGP_KERNEL_MATERN_SPLINE) || !(nu > 1.0) || !(nu <= 64.0))
-    return fail(h, CCGP_EINVAL, "ccgp_set_kernel: family must be CCGP_KERNEL_GAUSS, or CCGP_KERNEL_MATERN / CCGP_KERNEL_MATERN_SPLINE with 1 < nu <= 64");
+  if ((family != CCGP_KERNEL_MATERN && family != CCGP_KERNEL_MATERN_SPLINE) || !(nu > 1.0) || !(nu <= 10.0))
+    return fail(h, CCGP_EINVAL, "ccgp_set_kernel: family must be CCGP_KERNEL_GAUSS, or CCGP_KERNEL_MATERN / CCGP_KERNEL_MATERN_SPLINE with 1 < nu <= 10 (the range the quadrature is validated on; the scripts use 5)");
   h->fam.id = family;
   h->fam.nu = nu;
   h->fam.norm = 1.0 / (std::tgamma(nu) * std::pow(2.0, nu - 1.0));
@@ -718,21 +722,28 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     else
       log_prior = -4.0 * psi1 - 2.0 / theta1 - 6.0 * psi2 - 16.0 / theta2;
   }
+  // ONE factorisation per call (the reference runs two: solve(R) at HX:454 and the Cholesky inside dmnorm at
+  // HX:460): without R.Inv the batched evaluator; with it, a sweep that carries y', 1' AND the identity rows,
+  // so the likelihood, beta and R^-1 come out of the same elimination
   double ll = 0.0, beta = 0.0;
   int st = 0;
-  int rc = ccgp_loglik_batch(h, X, n, d, y, K, row.data(), 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0,
-                             &ll, &beta, &st);
-  if (rc < 0) return rc;
-  if (out_Rinv && (h->fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64)) {
-    // blocked path: one more sweep with the identity as extra rows, then R^-1 = Z Z' tile by tile
+  if (!out_Rinv) {
+    int rc = ccgp_loglik_batch(h, X, n, d, y, K, row.data(), 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, &ll, &beta,
+                               &st);
+    if (rc < 0) return rc;
+  } else {
+    CCGP_HIP(hipSetDevice(h->device));
+    const bool blocked = h->fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64;
     const int npad = round_up(n, kTile), nt = npad / kTile;
     size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
                   Carver::al(sizeof(double) * P) + Carver::al(sizeof(double) * (size_t)n * n) +
                   3 * Carver::al(sizeof(double) * 2) + 256;
     int rc2 = ensure_stage(h, need);
     if (rc2) return rc2;
-    rc2 = ensure_ws(h, blocked_ws_bytes(npad, 1, nt));
-    if (rc2) return rc2;
+    if (blocked) {
+      rc2 = ensure_ws(h, blocked_ws_bytes(npad, 1, nt));
+      if (rc2) return rc2;
+    }
     Carver c(h->stage);
     double* dX = c.take<double>((size_t)n * d);
     double* dy = c.take<double>(n);
@@ -748,34 +759,21 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     DrawView dv{dp, 1, K, d};
     dv.fam = h->fam;
     if (int frc = check_family(h, dv.fam, d, K)) return frc;
-    BlockedJob job{};
-    job.kind = kJobInverse; job.Rinv = dR;
-    BlockedWs w = blocked_carve(h->ws, npad, 1, nt);
-    blocked_loglik(h, dX, n, d, dy, dv, 0, 1, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, dll, dbt, dst, &job);
-    CCGP_LAUNCH_CHECK();
-    CCGP_HIP(hipMemcpyAsync(out_Rinv, dR, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
-    CCGP_HIP(hipStreamSynchronize(h->stream));
-  } else if (out_Rinv) {
-    size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * P) +
-                  Carver::al(sizeof(double) * (size_t)n * n) + 256;
-    int rc2 = ensure_stage(h, need);
-    if (rc2) return rc2;
-    Carver c(h->stage);
-    double* dX = c.take<double>((size_t)n * d);
-    double* dp = c.take<double>(P);
-    double* dR = c.take<double>((size_t)n * n);
-    int* dst = c.take<int>(1);
-    CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
-    CCGP_HIP(hipMemcpyAsync(dp, row.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
-    DrawView dv{dp, 1, K, d};
-    dv.fam = h->fam;
-    if (int frc = check_family(h, dv.fam, d, K)) return frc;
-    {
+    if (blocked) {
+      // identity as extra tile rows of the blocked sweep, then R^-1 = Z Z' tile by tile
+      BlockedJob job{};
+      job.kind = kJobInverse; job.Rinv = dR;
+      BlockedWs w = blocked_carve(h->ws, npad, 1, nt);
+      blocked_loglik(h, dX, n, d, dy, dv, 0, 1, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, w, dll, dbt, dst, &job);
+    } else {
       ScopedTimer t(h, CCGP_T_FUSED);
-      launch_small_inverse(h->stream, dX, n, d, dv, 0, dR, dst);
+      launch_small_inverse(h->stream, dX, n, d, dy, dv, 0, sigma2, dR, dll, dbt, dst);
     }
     CCGP_LAUNCH_CHECK();
     CCGP_HIP(hipMemcpyAsync(out_Rinv, dR, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipMemcpyAsync(&ll, dll, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipMemcpyAsync(&beta, dbt, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipMemcpyAsync(&st, dst, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CCGP_HIP(hipStreamSynchronize(h->stream));
   }
   *out_val = ll + log_jacob + log_prior;

@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -91,8 +92,8 @@ void launch_small_predict(hipStream_t s, const double* X, int n, int d, const do
                           int S, const double* Xtest, int m, double sigma2, double* mean,
                           double* var, double* beta, int* status);
 // Explicit inverse (solve(R), HX:454) and gradient for small n.
-void launch_small_inverse(hipStream_t s, const double* X, int n, int d, DrawView dv, int draw,
-                          double* Rinv, int* status);
+void launch_small_inverse(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int draw,
+                          double sigma2, double* Rinv, double* loglik, double* beta, int* status);
 int small_grad_chunks(int n, int d);
 // gpart: scratch of B * small_grad_chunks(n, d) * P doubles
 void launch_small_grad(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
@@ -156,14 +157,22 @@ double qigamma(double p, double alpha, double beta);
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Kernel attributes (dynamic-LDS ceiling) are per device: a process that holds handles on several
-// GPUs must set them once on EACH.  `mask` is a function-local static, one bit per device.
-inline bool first_use_on_device(unsigned long long& mask) {
+// GPUs must set them once on EACH.  `mask` is a function-local static, one bit per device.  Handles of
+// different shards (ccgp_multi) call in from different host threads, possibly for the same device: the
+// lock is held until the attributes are set, so nobody launches before they are.
+inline std::mutex& attr_mutex() {
+  static std::mutex m;
+  return m;
+}
+template <class F>
+inline void once_per_device(unsigned long long& mask, F set_attributes) {
+  std::lock_guard<std::mutex> guard(attr_mutex());
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
-  if (mask & bit) return false;
+  if (mask & bit) return;
+  set_attributes();
   mask |= bit;
-  return true;
 }
 
 // exp(x) for the covariance kernels (x = -theta-weighted squared distance, finite).  Same argument
@@ -240,7 +249,9 @@ __device__ inline double matern_corr(const KernelFamily& f, double z2) {
     const double t = k * hs;
     const double et = exp(t);
     const double c1 = 0.5 * (et + 1.0 / et) - 1.0;        // cosh t - 1
-    const double g = exp(-z * c1) * 0.5 * (exp(f.nu * t) + exp(-f.nu * t));
+    // exp(-z (cosh t - 1)) cosh(nu t) with each exponent formed BEFORE exponentiating: exp(nu t) alone
+    // overflows for large nu t long before the product does
+    const double g = 0.5 * (exp(f.nu * t - z * c1) + exp(-f.nu * t - z * c1));
     s += g;
     if (g < 1e-17 * s && f.nu * t < z * c1) break;
   }

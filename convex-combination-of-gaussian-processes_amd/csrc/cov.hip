@@ -145,10 +145,10 @@ size_t cov_lds(int d, int K) {
 // d = 64, K = 8 needs 78 KiB: above the 64 KiB a kernel gets without asking
 void cov_prepare() {
   static unsigned long long attr_mask = 0;
-  if (first_use_on_device(attr_mask)) {
+  once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)cov_kernel<0>, "cov_kernel<0>");
     raise_lds_limit((const void*)cov_kernel<1>, "cov_kernel<1>");
-  }
+  });
 }
 
 }  // namespace

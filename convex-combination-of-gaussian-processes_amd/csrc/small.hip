@@ -319,9 +319,9 @@ int small_pick_mtile(int n, int d, int m) {
 static void small_launch(hipStream_t s, const SmallArgs& a, int ndraws, int nchunks) {
   size_t lds = small_lds_bytes(a.n, a.d, a.kind == kRowsLoglik ? 0 : a.mtile);
   static unsigned long long attr_mask = 0;
-  if (first_use_on_device(attr_mask)) {
+  once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)small_kernel, "small_kernel");
-  }
+  });
   hipLaunchKernelGGL(small_kernel, dim3(ndraws, nchunks), dim3(256), lds, s, a);
 }
 
@@ -355,13 +355,14 @@ void launch_small_predict(hipStream_t s, const double* X, int n, int d, const do
   }
 }
 
-void launch_small_inverse(hipStream_t s, const double* X, int n, int d, DrawView dv, int draw,
-                          double* Rinv, int* status) {
+void launch_small_inverse(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int draw,
+                          double sigma2, double* Rinv, double* loglik, double* beta, int* status) {
   SmallArgs a{};
-  // y is not needed for the inverse; row n reuses X's first column as a harmless stand-in.
-  a.X = X; a.y = X; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
-  a.sigma2 = 1.0; a.mode = 0; a.kind = kRowsUnit; a.m = n; a.mtile = small_pick_mtile(n, d, n);
-  a.draw0 = draw; a.Rinv = Rinv; a.status = status;
+  // the same elimination that yields R^-1 carries the rows y', 1': likelihood and beta of logpost
+  // (HX:454-460) come out of this ONE factorisation (chunk 0 writes them)
+  a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
+  a.sigma2 = sigma2; a.mode = 0; a.kind = kRowsUnit; a.m = n; a.mtile = small_pick_mtile(n, d, n);
+  a.draw0 = draw; a.Rinv = Rinv; a.status = status; a.loglik = loglik; a.beta = beta;
   small_launch(s, a, 1, (n + a.mtile - 1) / a.mtile);
 }
 

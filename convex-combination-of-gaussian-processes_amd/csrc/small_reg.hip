@@ -386,9 +386,9 @@ void launch_one(hipStream_t s, const RegArgs& a) {
   constexpr int MPW = 256 / (G * G);
   const size_t lds = reg_lds_bytes<G, NB, NE>(a);
   static unsigned long long attr_mask = 0;
-  if (first_use_on_device(attr_mask)) {
+  once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)small_reg_kernel<G, NB, NE>, "small_reg_kernel");
-  }
+  });
   const int chunks = NE > 1 ? (a.m + (G * NE - 2) - 1) / (G * NE - 2) : 1;
   const int kMaxGrid = 1 << 20;
   RegArgs c = a;

@@ -352,6 +352,10 @@ def Combined_GP_fit(gp, D_train, y_train, D_new, start, N_max, samp_size, alpha_
     posterior draws (laplace + Metro) -> predictions with intervals at D.new."""
     rng = np.random.default_rng(rng)
     if sigma2 is None:
+        if getattr(gp, "script", "") in ("D1", "D1F"):
+            # the 1-D scripts take sigma2 from their own Matern MLEs() (D1:455-471, D1:994-995), a comparator model
+            # that is out of scope here; the Gaussian ordinary-kriging MLE below is what the OTHER scripts get from mlegp
+            raise ValueError("Combined_GP_fit: pass sigma2 for the 1-D scripts (they take it from MLEs(), D1:994-995)")
         sigma2, _, _ = ordinary_kriging_sigma2(gp.h, D_train, y_train)
     net = net_samp_size or samp_size
     ff = factors_frame(gp, start, N_max, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train, net,

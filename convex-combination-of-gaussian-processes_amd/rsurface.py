@@ -210,10 +210,26 @@ class CombinedGP:
         draws = np.atleast_2d(np.asarray(draws, dtype=np.float64))
         return np.stack([self._row(D_train, *row) for row in draws])
 
-    def prediction_table(self, D_test, draws, D_train, sigma2, y_train):
+    def prediction_table(self, D_test, draws, D_train, sigma2, y_train, as_written=False):
         """The deterministic part of prediction()/compare.GP (HX:686-693, HX:713-725): the
         (draw x test point) mean and variance tables and y.hat = colMeans(mean).  The
-        rnorm/quantile interval step (HX:696-699) needs R's RNG and is out of scope."""
+        rnorm/quantile interval step (HX:696-699) needs R's RNG and is out of scope.
+
+        script "ADV": the reference trains with R2 = corr.matrix.ISO(D, lambda) (ADV:417, ADV:456) but its
+        predict.post builds r with theta1 * (1 + lambda) (ADV:672) -- two different second components.  The
+        batched device path uses ONE kernel for R and r (the training one: what the posterior draws were
+        fitted under).  as_written=True reproduces ADV:672 instead, through the literal per-draw path
+        (factors.frame row + predict.post per test site): exact to the script, S * m small device calls."""
+        if as_written and self.script == "ADV":
+            D_test = np.atleast_2d(np.asarray(D_test, dtype=np.float64))
+            frame = self.factors_frame_from_draws(draws, D_train, sigma2, y_train)
+            S, m = frame.shape[0], D_test.shape[0]
+            mean, var = np.empty((S, m)), np.empty((S, m))
+            for s in range(S):
+                for t in range(m):
+                    mean[s, t], var[s, t] = self.predict_post(D_test[t], D_train, frame[s], sigma2)[0]
+            return dict(mean=mean, var=var, beta=frame[:, 3], status=np.zeros(S, dtype=np.int32),
+                        y_hat=mean.mean(axis=0))
         params = self.draws_to_params(D_train, draws)
         mean, var, beta, status = self.h.predict_batch(D_train, y_train, 2, params, D_test, sigma2)
         return dict(mean=mean, var=var, beta=beta, status=status, y_hat=mean.mean(axis=0))

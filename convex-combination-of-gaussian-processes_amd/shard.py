@@ -26,9 +26,19 @@ def shard_sizes(total, world):
     return [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
 
 
+def gather_device(backend, tensor_device):
+    """Where the all-gather buffers must live: RCCL ("nccl") only moves device memory, so host arrays (what the
+    C ABI's host-pointer entry points return) are staged through this rank's GPU; gloo gathers in place."""
+    import torch
+    if backend == "nccl" and tensor_device.type != "cuda":
+        return torch.device("cuda", torch.cuda.current_device())
+    return tensor_device
+
+
 def all_gather_rows(local, total, group=None):
     """Gather variable-length per-rank slices of a [rows, ...] float64 array into the full
-    array on every rank (one all_gather of equal-size padded buffers)."""
+    array on every rank (one all_gather of equal-size padded buffers).  numpy in -> numpy out; a tensor
+    comes back on the device it came from."""
     import torch
     import torch.distributed as dist
 
@@ -38,14 +48,20 @@ def all_gather_rows(local, total, group=None):
     sizes = shard_sizes(total, world)
     is_t = isinstance(local, torch.Tensor)
     t = local if is_t else torch.from_numpy(np.ascontiguousarray(local))
+    home = t.device
+    dev = gather_device(dist.get_backend(group), home)
+    if dev != home:
+        t = t.to(dev)
     mx = max(sizes)
     pad_shape = (mx,) + tuple(t.shape[1:])
-    buf = torch.zeros(pad_shape, dtype=t.dtype, device=t.device)
+    buf = torch.zeros(pad_shape, dtype=t.dtype, device=dev)
     buf[: t.shape[0]] = t
     outs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf, group=group)
     full = torch.cat([o[: sizes[r]] for r, o in enumerate(outs)], dim=0)
-    return full if is_t else full.cpu().numpy()
+    if dev != home:
+        full = full.to(home)
+    return full if is_t else full.numpy()
 
 
 def sharded_loglik(evaluate, params, group=None):

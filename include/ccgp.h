@@ -23,7 +23,8 @@
  *     (ANI:399-406) is theta_1 = (theta1,theta2), theta_2 = (1+lambda)(theta1,theta2).
  *   - the caller owns every buffer; the library allocates only device scratch kept
  *     in the handle.  A handle is bound to ONE HIP device and is not re-entrant
- *     (R is single-threaded; one handle per host thread / per GPU process).
+ *     (R is single-threaded; one handle per host thread / per GPU process); ccgp_multi
+ *     (below) puts several devices behind one call.
  *   - return value: 0 ok, <0 error (ccgp_last_error), >0 = number of evaluations in
  *     the batch whose factorisation met a non-positive pivot.  Per-evaluation
  *     status[b] = 0 or 1-based index of the first bad pivot; such an evaluation
@@ -77,7 +78,7 @@ int ccgp_set_stream(ccgp_handle* h, void* hip_stream);
  * CCGP_KERNEL_GAUSS : R_c[i,j] = exp(-sum_k theta_ck (x_ik - x_jk)^2)     corr.matrix HX:328-337, ANI:351-360
  * CCGP_KERNEL_MATERN: the 1-D scripts' Matern.corr.func(nu, h, theta) D1:348-351,
  *                     R_c[i,j] = z^nu K_nu(z) / (Gamma(nu) 2^(nu-1)),  z = 2 sqrt(nu) |x_i - x_j| / theta_c;
- *                     d must be 1 and a draw is (w_1..w_K, theta_1..theta_K); 1 < nu <= 64 (D1:1080 uses 5).
+ *                     d must be 1 and a draw is (w_1..w_K, theta_1..theta_K); 1 < nu <= 10, the range the quadrature is validated on (D1:1080 uses 5).
  * Replaces corr.matrix(nu, X, theta) D1:368-374, corr.vec D1:383-389 and everything built on them
  * (Mixed.corr.matrix D1:575-584, logpost D1:609-641, predict.post D1:794-812) through the same entry
  * points as the Gaussian family; the analytic gradient is Gaussian-only.
@@ -199,6 +200,34 @@ int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, dou
  * n x d (column-major each, design b at Xs + b*n*d) that share ONE parameter row; n <= 128. */
 int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, int B, int K,
                               const double* params, double* out_logdet, int* status);
+
+/* ---- several GPUs behind ONE host process (csrc/multi.cpp) ------------------------------
+ * The drop-in host is R: one single-threaded process.  A ccgp_multi owns one handle per device; the three
+ * batched entry points below take the same arguments as their single-device forms, cut the batch into
+ * contiguous shards (the grid by grid ROW, so that a row's mean over its Halton nodes stays on one device,
+ * HX:574), run the shards concurrently and deliver every result in the caller's host buffers at the
+ * shard's offset -- plain device-to-host copies: the consumer (which.max, HX:593-594) is the host, so an
+ * all-gather into every GPU's memory would be a copy nobody reads.  Results are bit-identical to the
+ * single-device call whatever the number of shards (every evaluation is computed by its own workgroups).
+ * devices = NULL means 0 .. n_devices-1; a device may be listed more than once (shards then share it).
+ * Return values as for the single-device calls (sum over shards of the failed evaluations; the first
+ * negative shard return otherwise, message in ccgp_multi_last_error). */
+typedef struct ccgp_multi ccgp_multi;
+int ccgp_multi_create(int n_devices, const int* devices, ccgp_multi** out);
+int ccgp_multi_destroy(ccgp_multi* m);
+int ccgp_multi_count(const ccgp_multi* m);
+ccgp_handle* ccgp_multi_handle(ccgp_multi* m, int i); /* per-shard handle: workspace limit, options */
+const char* ccgp_multi_last_error(const ccgp_multi* m);
+int ccgp_multi_set_kernel(ccgp_multi* m, int family, double nu);
+int ccgp_multi_loglik_batch(ccgp_multi* m, const double* X, int n, int d, const double* y, int K,
+                            const double* params, int B, double sigma2, int mean_mode, double tau2,
+                            double* out_loglik, double* out_beta, int* status);
+int ccgp_multi_grid_marginal(ccgp_multi* m, const double* X, int n, int d, const double* y, double sigma2,
+                             const double* hyper, int G, int N, double tau, int take_log,
+                             double aniso_lambda, double* out, int* out_argmax, double* out_logs);
+int ccgp_multi_predict_batch(ccgp_multi* m, const double* X, int n, int d, const double* y, int K,
+                             const double* params, int S, const double* Xtest, int mt, double sigma2,
+                             double* out_mean, double* out_var, double* out_beta, int* status);
 
 /* ---- measurement hooks (bench.py / rocprof; not part of the R surface) ---------------
  * Time, with HIP events on the handle's stream, every launch group of the most recent

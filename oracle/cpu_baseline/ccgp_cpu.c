@@ -30,9 +30,12 @@ typedef void (*potrf_fn)(const char*, const int*, double*, const int*, int*);
 typedef void (*trsv_fn)(const char*, const char*, const char*, const int*, const double*, const int*, double*,
                         const int*);
 typedef void (*setthr_fn)(int);
+typedef int (*getthr_fn)(void);
 
 static potrf_fn g_potrf = 0;
 static trsv_fn g_trsv = 0;
+static setthr_fn g_setthr = 0;
+static getthr_fn g_getthr = 0;
 
 /* returns 1 when dpotrf / dtrsv were bound from `path`, 0 when the built-in factorisation will be used */
 int ccgp_cpu_init(const char* path) {
@@ -43,17 +46,34 @@ int ccgp_cpu_init(const char* path) {
   const char* pn[] = {"scipy_dpotrf_", "dpotrf_"};
   const char* tn[] = {"scipy_dtrsv_", "dtrsv_"};
   const char* sn[] = {"scipy_openblas_set_num_threads", "openblas_set_num_threads"};
+  const char* gn[] = {"scipy_openblas_get_num_threads", "openblas_get_num_threads"};
   potrf_fn p = 0;
   trsv_fn t = 0;
   setthr_fn s = 0;
+  getthr_fn g = 0;
   for (int i = 0; i < 2 && !p; ++i) p = (potrf_fn)dlsym(h, pn[i]);
   for (int i = 0; i < 2 && !t; ++i) t = (trsv_fn)dlsym(h, tn[i]);
   for (int i = 0; i < 2 && !s; ++i) s = (setthr_fn)dlsym(h, sn[i]);
-  if (!p || !t) return 0;
-  if (s) s(1); /* one evaluation per core: no threading inside an evaluation */
+  for (int i = 0; i < 2 && !g; ++i) g = (getthr_fn)dlsym(h, gn[i]);
+  /* One evaluation per core means no threading INSIDE an evaluation.  The library instance is shared with
+   * scipy in this process, so its thread count is set to 1 by the CALLING thread around each batch and put
+   * back afterwards (blas_single / blas_restore); without both hooks the built-in factorisation is used */
+  if (!p || !t || !s || !g) return 0;
   g_potrf = p;
   g_trsv = t;
+  g_setthr = s;
+  g_getthr = g;
   return 1;
+}
+
+static int blas_single(void) {
+  if (!g_setthr) return 0;
+  const int prev = g_getthr();
+  g_setthr(1);
+  return prev;
+}
+static void blas_restore(int prev) {
+  if (g_setthr && prev > 0) g_setthr(prev);
 }
 
 /* plain blocked Cholesky (lower, column-major), used only when no LAPACK could be bound */
@@ -163,6 +183,7 @@ int ccgp_cpu_loglik_batch(const double* X, int n, int d, const double* y, int K,
                           int threads) {
   int bad = 0;
   if (threads < 1) threads = omp_get_max_threads();
+  const int prev_blas = blas_single();
 #pragma omp parallel num_threads(threads) reduction(+ : bad)
   {
     double* A = (double*)malloc(sizeof(double) * (size_t)n * n);
@@ -209,6 +230,7 @@ int ccgp_cpu_loglik_batch(const double* X, int n, int d, const double* y, int K,
     }
     free(A); free(u); free(xt); free(zy); free(z1);
   }
+  blas_restore(prev_blas);
   return bad;
 }
 
@@ -217,6 +239,7 @@ int ccgp_cpu_predict_batch(const double* X, int n, int d, const double* y, int K
                            const double* Xt, int m, double sigma2, double* mean, double* var, int threads) {
   int bad = 0;
   if (threads < 1) threads = omp_get_max_threads();
+  const int prev_blas = blas_single();
 #pragma omp parallel num_threads(threads) reduction(+ : bad)
   {
     double* A = (double*)malloc(sizeof(double) * (size_t)n * n);
@@ -267,6 +290,7 @@ int ccgp_cpu_predict_batch(const double* X, int n, int d, const double* y, int K
     }
     free(A); free(u); free(xt); free(zy); free(z1); free(r);
   }
+  blas_restore(prev_blas);
   return bad;
 }
 

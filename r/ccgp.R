@@ -4,7 +4,9 @@
 # Usage inside any of the reference scripts, AFTER its own function definitions and before
 # its "Simulation starts here" driver block:
 #
-#     ccgp.script <- "HX"          # which script's variant: HX, GV, ISO, ADV, ANI, BSQ, D1 (1-D, Matern)
+#     ccgp.script <- "HX"          # which script's variant: HX, GV, ISO, ADV, ANI, BSQ, D1 (1-D, Matern),
+#                                  #   D1F (1-D, Matern + cubic spline)
+#     Sys.setenv(CCGP_DEVICES = "8")   # optional: shard the batched calls over 8 GPUs of this node
 #     source("r/ccgp.R")
 #
 # Everything that calls these functions (Metro, laplace via logpost.val, factors.frame,
@@ -15,7 +17,7 @@ dyn.load(Sys.getenv("CCGP_R_SHIM", "ccgpR.so"))
 
 if (!exists("ccgp.script")) ccgp.script <- "HX"
 .ccgp.aniso <- ccgp.script == "ANI"
-.ccgp.prior <- switch(ccgp.script, HX = 0L, ADV = 0L, GV = 1L, ISO = 2L, BSQ = 2L, ANI = 3L, D1 = 2L)
+.ccgp.prior <- switch(ccgp.script, HX = 0L, ADV = 0L, GV = 1L, ISO = 2L, BSQ = 2L, ANI = 3L, D1 = 2L, D1F = 2L)
 
 # (p, theta1, theta2[, lambda]) -> the C-ABI parameter row (w_1, w_2, theta_1k.., theta_2k..)
 .ccgp.row <- function(d, p, theta1, theta2, lambda = NULL) {
@@ -156,5 +158,46 @@ if (ccgp.script == "D1") {
                  matrix(pars[(6 + 2 * n):(5 + 2 * n + n^2)], nrow = n), as.double(sigma2))
     colnames(out) <- c("mean", "var")
     out
+  }
+}
+
+
+# ---- two-family 1-D script (1D Combined GP Two Families Public.R): Matern(nu) + non-negative cubic spline ----
+if (ccgp.script == "D1F") {
+  .ccgp.two <- function(nu, expr) {             # family 2 = (Matern(nu, theta1), spline(theta2)) for one call
+    .Call("ccgp_R_set_kernel", 2L, as.double(nu))
+    on.exit(.Call("ccgp_R_set_kernel", 0L, 0))
+    force(expr)
+  }
+  corr.matrix.spline <- function(X, theta)                                                # D1F:394-400
+    .ccgp.two(5, .Call("ccgp_R_mixed_corr_matrix", as.matrix(X), 2L, c(0, 1, 1, theta)))   # w = (0, 1): spline only
+  corr.vec.spline <- function(x, X, theta)                                                # D1F:407-413
+    .ccgp.two(5, as.vector(.Call("ccgp_R_mixed_corr_cross", matrix(as.double(x), nrow = 1), as.matrix(X), 2L,
+                                 c(0, 1, 1, theta))))
+  corr.matrix.combined <- function(X, p, theta1, theta2, nu)                              # D1F:453-462
+    .ccgp.two(nu, .Call("ccgp_R_mixed_corr_matrix", as.matrix(X), 2L, c(p, 1 - p, theta1, theta2)))
+  # D1F:470-480 as written: the division by p^2 + (1-p)^2 sits after the return, so r is NOT normalised;
+  # the device keeps that (include/ccgp.h, CCGP_KERNEL_MATERN_SPLINE)
+  corr.vec.combined <- function(x, X, p, theta1, theta2, nu)
+    .ccgp.two(nu, as.vector(.Call("ccgp_R_mixed_corr_cross", matrix(as.double(x), nrow = 1), as.matrix(X), 2L,
+                                  c(p, 1 - p, theta1, theta2))))
+  logpost <- function(D.train, theta, y, sigma2, nu)                                      # D1F:576-602
+    .ccgp.two(nu, .ccgp.logpost(D.train, theta, y, sigma2, NULL))
+  predict.post <- function(x.new, D.train, pars, sigma2, nu) {                            # D1F:737-754
+    n <- dim(D.train)[1]
+    pars <- as.numeric(pars)
+    r <- corr.vec.combined(x.new, D.train, pars[1], pars[2], pars[3], nu)
+    out <- .Call("ccgp_R_predict_from_factors", matrix(r, nrow = 1), pars[4], pars[5:(4 + n)],
+                 pars[(5 + n):(4 + 2 * n)], pars[5 + 2 * n],
+                 matrix(pars[(6 + 2 * n):(5 + 2 * n + n^2)], nrow = n), as.double(sigma2))
+    colnames(out) <- c("mean", "var")
+    out
+  }
+  # batched (draw x site) tables with this family: the device uses the same un-normalised r
+  ccgp.prediction.table <- function(D.test, draws, D.train, sigma2, y.train, nu) {
+    P <- t(apply(as.matrix(draws), 1, function(r) c(r[1], 1 - r[1], r[2], r[3])))
+    r <- .ccgp.two(nu, .Call("ccgp_R_predict_batch", as.matrix(D.train), as.double(y.train), 2L, P,
+                             as.matrix(D.test), as.double(sigma2)))
+    list(mean = r[[1]], var = r[[2]], beta = r[[3]])
   }
 }

@@ -1,8 +1,10 @@
 /*
  * .Call() shim between R and libccgp (include/ccgp.h).
  *
- * NOT compiled in this repository's build: the build container has no R (no
- * Rinternals.h, no libR.so).  A maintainer builds it on a machine with R and ROCm:
+ * NOT compiled against R in this repository's build: the build container has no R (no
+ * Rinternals.h, no libR.so).  tests/test_r_shim_compiles.py compiles it against include/ccgp.h with a
+ * minimal mock of the R headers (tests/r_mock/) -- a guard against prototype drift, nothing more.
+ * A maintainer builds it on a machine with R and ROCm:
  *
  *     R CMD SHLIB -o ccgpR.so r/ccgp_shim.c -I include \
  *         -L convex-combination-of-gaussian-processes_amd/csrc -lccgp
@@ -17,9 +19,14 @@
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "ccgp.h"
 
 static ccgp_handle* g_handle = NULL; /* R is single-threaded: one handle per process */
+static ccgp_multi* g_multi = NULL;   /* CCGP_DEVICES=k (k > 1) or a comma list: the batched calls are sharded */
+static int g_multi_tried = 0;
 
 static ccgp_handle* handle(void) {
   if (!g_handle) {
@@ -34,8 +41,41 @@ static ccgp_handle* handle(void) {
   return g_handle;
 }
 
+/* CCGP_DEVICES="8" -> devices 0..7;  CCGP_DEVICES="0,2,4" -> that list.  NULL when unset or a single device:
+ * the batched entry points then use the one handle. */
+static ccgp_multi* multi(void) {
+  if (!g_multi_tried) {
+    g_multi_tried = 1;
+    const char* e = getenv("CCGP_DEVICES");
+    if (e && *e) {
+      int devs[64], k = 0;
+      if (strchr(e, ',')) {
+        const char* q = e;
+        while (*q && k < 64) {
+          devs[k++] = atoi(q);
+          q = strchr(q, ',');
+          if (!q) break;
+          ++q;
+        }
+      } else {
+        k = atoi(e);
+        if (k > 64) k = 64;
+        for (int i = 0; i < k; ++i) devs[i] = i;
+      }
+      if (k > 1 && ccgp_multi_create(k, devs, &g_multi) != CCGP_OK) {
+        g_multi = NULL;
+        Rf_warning("libccgp: CCGP_DEVICES=%s could not be opened; using one device", e);
+      }
+    }
+  }
+  return g_multi;
+}
+
 static void warn_rc(int rc) {
   if (rc < 0) Rf_warning("libccgp error %d: %s", rc, ccgp_last_error(g_handle));
+}
+static void warn_rc_multi(int rc) {
+  if (rc < 0) Rf_warning("libccgp error %d: %s", rc, ccgp_multi_last_error(g_multi));
 }
 
 static void fill_na(double* p, R_xlen_t n) {
@@ -114,10 +154,19 @@ SEXP ccgp_R_loglik_batch(SEXP X, SEXP y, SEXP K, SEXP params, SEXP sigma2, SEXP 
   SEXP ll = PROTECT(Rf_allocVector(REALSXP, B));
   SEXP beta = PROTECT(Rf_allocVector(REALSXP, B));
   SEXP st = PROTECT(Rf_allocVector(INTSXP, B));
-  int rc = ccgp_loglik_batch(handle(), REAL(X), n, d, REAL(y), Rf_asInteger(K), REAL(params), B,
-                             Rf_asReal(sigma2), Rf_asInteger(mean_mode), Rf_asReal(tau2), REAL(ll),
-                             REAL(beta), INTEGER(st));
-  if (rc < 0) { warn_rc(rc); fill_na(REAL(ll), B); fill_na(REAL(beta), B); }
+  int rc;
+  if (multi()) {
+    rc = ccgp_multi_loglik_batch(g_multi, REAL(X), n, d, REAL(y), Rf_asInteger(K), REAL(params), B,
+                                 Rf_asReal(sigma2), Rf_asInteger(mean_mode), Rf_asReal(tau2), REAL(ll),
+                                 REAL(beta), INTEGER(st));
+    warn_rc_multi(rc);
+  } else {
+    rc = ccgp_loglik_batch(handle(), REAL(X), n, d, REAL(y), Rf_asInteger(K), REAL(params), B,
+                           Rf_asReal(sigma2), Rf_asInteger(mean_mode), Rf_asReal(tau2), REAL(ll),
+                           REAL(beta), INTEGER(st));
+    warn_rc(rc);
+  }
+  if (rc < 0) { fill_na(REAL(ll), B); fill_na(REAL(beta), B); }
   for (int i = 0; i < B; ++i)
     if (ISNAN(REAL(ll)[i])) { REAL(ll)[i] = NA_REAL; REAL(beta)[i] = NA_REAL; }
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 3));
@@ -133,10 +182,19 @@ SEXP ccgp_R_grid_marginal(SEXP X, SEXP y, SEXP sigma2, SEXP hyper, SEXP N, SEXP 
                           SEXP aniso_lambda) {
   int n = Rf_nrows(X), d = Rf_ncols(X), G = Rf_nrows(hyper), arg = -1;
   SEXP vals = PROTECT(Rf_allocVector(REALSXP, G));
-  int rc = ccgp_grid_marginal(handle(), REAL(X), n, d, REAL(y), Rf_asReal(sigma2), REAL(hyper), G,
-                              Rf_asInteger(N), Rf_asReal(tau), Rf_asInteger(take_log),
-                              Rf_asReal(aniso_lambda), REAL(vals), &arg, NULL);
-  if (rc < 0) { warn_rc(rc); fill_na(REAL(vals), G); }
+  int rc;
+  if (multi()) {   /* sharded by grid row over the devices of CCGP_DEVICES */
+    rc = ccgp_multi_grid_marginal(g_multi, REAL(X), n, d, REAL(y), Rf_asReal(sigma2), REAL(hyper), G,
+                                  Rf_asInteger(N), Rf_asReal(tau), Rf_asInteger(take_log),
+                                  Rf_asReal(aniso_lambda), REAL(vals), &arg, NULL);
+    warn_rc_multi(rc);
+  } else {
+    rc = ccgp_grid_marginal(handle(), REAL(X), n, d, REAL(y), Rf_asReal(sigma2), REAL(hyper), G,
+                            Rf_asInteger(N), Rf_asReal(tau), Rf_asInteger(take_log),
+                            Rf_asReal(aniso_lambda), REAL(vals), &arg, NULL);
+    warn_rc(rc);
+  }
+  if (rc < 0) fill_na(REAL(vals), G);
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
   SET_VECTOR_ELT(out, 0, vals);
   SET_VECTOR_ELT(out, 1, Rf_ScalarInteger(arg + 1)); /* which.max is 1-based in R */
@@ -150,9 +208,17 @@ SEXP ccgp_R_predict_batch(SEXP X, SEXP y, SEXP K, SEXP params, SEXP Xtest, SEXP 
   SEXP mean = PROTECT(Rf_allocMatrix(REALSXP, S, m));
   SEXP var = PROTECT(Rf_allocMatrix(REALSXP, S, m));
   SEXP beta = PROTECT(Rf_allocVector(REALSXP, S));
-  int rc = ccgp_predict_batch(handle(), REAL(X), n, d, REAL(y), Rf_asInteger(K), REAL(params), S,
-                              REAL(Xtest), m, Rf_asReal(sigma2), REAL(mean), REAL(var), REAL(beta), NULL);
-  if (rc < 0) { warn_rc(rc); fill_na(REAL(mean), (R_xlen_t)S * m); fill_na(REAL(var), (R_xlen_t)S * m); }
+  int rc;
+  if (multi()) {   /* sharded over the posterior draws */
+    rc = ccgp_multi_predict_batch(g_multi, REAL(X), n, d, REAL(y), Rf_asInteger(K), REAL(params), S,
+                                  REAL(Xtest), m, Rf_asReal(sigma2), REAL(mean), REAL(var), REAL(beta), NULL);
+    warn_rc_multi(rc);
+  } else {
+    rc = ccgp_predict_batch(handle(), REAL(X), n, d, REAL(y), Rf_asInteger(K), REAL(params), S,
+                            REAL(Xtest), m, Rf_asReal(sigma2), REAL(mean), REAL(var), REAL(beta), NULL);
+    warn_rc(rc);
+  }
+  if (rc < 0) { fill_na(REAL(mean), (R_xlen_t)S * m); fill_na(REAL(var), (R_xlen_t)S * m); }
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 3));
   SET_VECTOR_ELT(out, 0, mean);
   SET_VECTOR_ELT(out, 1, var);
@@ -210,10 +276,15 @@ SEXP ccgp_R_mixed_logdet_designs(SEXP Xs, SEXP n, SEXP d, SEXP K, SEXP params) {
 }
 
 /* correlation family for the calls that follow: 0 = Gaussian, 1 = Matern(nu) of the 1-D script
- * (Matern.corr.func, 1D Combined GP Public.R:348-351) */
+ * (Matern.corr.func, 1D Combined GP Public.R:348-351), 2 = Matern(nu) + cubic spline of the two-family script
+ * (1D Combined GP Two Families Public.R:346-357, 453-462) */
 SEXP ccgp_R_set_kernel(SEXP family, SEXP nu) {
   int rc = ccgp_set_kernel(handle(), Rf_asInteger(family), Rf_asReal(nu));
   warn_rc(rc);
+  if (rc == 0 && multi()) {
+    rc = ccgp_multi_set_kernel(g_multi, Rf_asInteger(family), Rf_asReal(nu));
+    warn_rc_multi(rc);
+  }
   return Rf_ScalarInteger(rc);
 }
 
@@ -242,4 +313,5 @@ void R_init_ccgpR(DllInfo* dll) {
 void R_unload_ccgpR(DllInfo* dll) {
   (void)dll;
   if (g_handle) { ccgp_destroy(g_handle); g_handle = NULL; }
+  if (g_multi) { ccgp_multi_destroy(g_multi); g_multi = NULL; }
 }

@@ -676,3 +676,30 @@ def test_two_family_1d_surface_vs_fixture(handle):
     with pytest.raises(api.CcgpError):                       # the pair is K = 2 by definition
         handle.mixed_corr_matrix(X.reshape(-1, 1), 3, np.array([0.3, 0.3, 0.4, 0.5, 0.6, 0.7]))
     handle.set_kernel(api.KERNEL_GAUSS)
+
+
+def test_adv_prediction_tables_batched_and_as_written(handle):
+    """ADV trains with R2 = corr.matrix.ISO(D, lambda) (ADV:417) and predicts with theta1 * (1 + lambda)
+    (ADV:672).  The batched table uses the training kernel for r; as_written=True reproduces the script."""
+    from ccgp_amd.rsurface import CombinedGP
+    gd = golden("adv_golden.json")
+    D14, y14 = load_maximin(14), np.array(gd["y"])
+    Dt = np.array([[0.21, 0.4], [0.66, 0.12], [0.5, 0.93]])
+    draws = np.array([[0.8, 0.9, 6.0], [0.65, 1.4, 9.0]])                  # (p, theta1, lambda)
+    s2 = gd["sigma2"]
+    gp = CombinedGP("ADV", handle=handle)
+    batched = gp.prediction_table(Dt, draws, D14, s2, y14)
+    literal = gp.prediction_table(Dt, draws, D14, s2, y14, as_written=True)
+    for s, (p, t1, lam) in enumerate(draws):
+        R_inv = orc.solve_inverse(orc.mixed_corr_matrix_iso(D14, p, t1, lam))
+        beta = orc.beta_mle(R_inv, y14)
+        mf, v1, v2 = orc.factors(R_inv, beta, y14)
+        for t in range(Dt.shape[0]):
+            consistent = orc.predict_post_from_factors(orc.mixed_corr_vec_iso(Dt[t], D14, p, t1, lam), beta, mf, v1, v2, R_inv, s2)
+            written = orc.predict_post_from_factors(orc.mixed_corr_vec_iso(Dt[t], D14, p, t1, t1 * (1.0 + lam)), beta, mf, v1, v2,
+                                                    R_inv, s2)
+            assert batched["mean"][s, t] == pytest.approx(consistent[0], rel=1e-7)
+            assert batched["var"][s, t] == pytest.approx(consistent[1], rel=1e-5, abs=1e-9)
+            assert literal["mean"][s, t] == pytest.approx(written[0], rel=1e-7)
+            assert literal["var"][s, t] == pytest.approx(written[1], rel=1e-5, abs=1e-9)
+    assert np.max(np.abs(batched["mean"] - literal["mean"])) > 1e-3     # the two really are different predictors

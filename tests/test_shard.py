@@ -100,3 +100,17 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     want = np.array([orc.loglik_general(D, y, *orc.unpack_params(r, 2, 2), 0.4)[0] for r in params])
     np.testing.assert_array_equal(r0["ll"], want)
     assert r0["ll"].shape == (13,) and r0["mean"].shape == (13, 3)
+
+
+def test_gather_buffers_are_staged_on_the_gpu_for_rccl():
+    """RCCL ("nccl") moves device memory only: host arrays coming out of the C ABI must be staged through the
+    rank's GPU; gloo gathers host memory in place; device tensors stay where they are."""
+    import torch
+    from ccgp_amd import shard as sh
+    cpu = torch.device("cpu")
+    assert sh.gather_device("gloo", cpu) == cpu
+    cuda1 = torch.device("cuda", 1)
+    assert sh.gather_device("nccl", cuda1) == cuda1
+    assert sh.gather_device("gloo", cuda1) == cuda1
+    if torch.cuda.is_available():
+        assert sh.gather_device("nccl", cpu).type == "cuda"

@@ -48,7 +48,7 @@ def test_matern_quadrature_rule_of_the_device_kernel():
         while True:
             t = k * hs
             c1 = math.cosh(t) - 1.0
-            g = math.exp(-z * c1) * math.cosh(nu * t)
+            g = 0.5 * (math.exp(nu * t - z * c1) + math.exp(-nu * t - z * c1))   # exponents formed first: no overflow
             s += g
             k += 1
             if (g < 1e-17 * s and nu * t < z * c1) or k > 6000:

@@ -506,6 +506,28 @@ def main():
                                      "failed_draws": int(sum(int((t[8] != 0).sum().item()) for t in dsets))})
             for entry, key in zip(out["secondary"], ("cfg2", "cfg3", "cfg5")):
                 entry["cpu"] = cpu_sec.get(key)
+            # prediction at a second test set from factors kept in HBM, against re-factorising
+            if args.workload == "cfg4" and n == 4096:
+                Sf, mf_ = 16, 128
+                Xt = np.random.default_rng(5).random((mf_, d))
+                t1 = time.perf_counter()
+                fs = h.factor_batch(X, y, K, P[:Sf], sigma2)
+                t_fac = time.perf_counter() - t1
+                fs.predict(Xt)
+                t1 = time.perf_counter()
+                m_a, v_a = fs.predict(Xt)
+                t_keep = time.perf_counter() - t1
+                h.predict_batch(X, y, K, P[:Sf], Xt, sigma2)
+                t1 = time.perf_counter()
+                m_b, v_b, _, _ = h.predict_batch(X, y, K, P[:Sf], Xt, sigma2)
+                t_full = time.perf_counter() - t1
+                out["secondary"].append({
+                    "workload": "cfg4 prediction: n=4096, %d draws, %d test sites" % (Sf, mf_),
+                    "value": Sf * mf_ / t_keep, "unit": "(draw, test point) predictions/s from a kept factor set",
+                    "ms_from_factorset": 1e3 * t_keep, "ms_refactorising": 1e3 * t_full, "ms_factor_batch": 1e3 * t_fac,
+                    "factorset_bytes": fs.nbytes, "identical": bool(np.array_equal(m_a, m_b) and np.array_equal(v_a, v_b)),
+                    "cpu": None})
+                fs.free()
         print(json.dumps(out))
     h.close()
     if world > 1:

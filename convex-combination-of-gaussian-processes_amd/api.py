@@ -60,6 +60,11 @@ SIGNATURES = {
     "ccgp_predict_batch_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_int, c_void_p, c_int, c_double, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
+    "ccgp_factor_batch": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_int, _dp, c_int, c_double, POINTER(c_void_p),
+                                  _dp, _dp, _ip]),
+    "ccgp_predict_from_factorset": (c_int, [c_void_p, c_void_p, _dp, c_int, _dp, _dp]),
+    "ccgp_factorset_bytes": (c_size_t, [c_void_p]),
+    "ccgp_factorset_free": (c_int, [c_void_p, c_void_p]),
     "ccgp_factors": (c_int, [c_void_p, _dp, c_double, _dp, c_int, _dp]),
     "ccgp_predict_from_factors": (c_int, [c_void_p, _dp, c_int, c_int, c_double, _dp, _dp, c_double,
                                           _dp, c_double, _dp, _dp]),
@@ -130,6 +135,43 @@ def qigamma(p, alpha, beta):
     if rc:
         raise CcgpError(rc, "ccgp_qigamma")
     return out
+
+
+class FactorSet:
+    """S Cholesky factors kept in HBM (ccgp_factor_batch); predict(Xtest) -> (mean[S, m], var[S, m])."""
+
+    def __init__(self, handle, ptr, S, loglik, beta, status):
+        self._handle, self._fs, self.S = handle, ptr, S
+        self.loglik, self.beta, self.status = loglik, beta, status
+
+    @property
+    def nbytes(self):
+        return int(lib().ccgp_factorset_bytes(self._fs))
+
+    def predict(self, Xtest):
+        Xtest = _f(np.atleast_2d(Xtest))
+        m = Xtest.shape[0]
+        mean = np.empty((self.S, m), dtype=np.float64, order="F")
+        var = np.empty((self.S, m), dtype=np.float64, order="F")
+        self._handle._chk(lib().ccgp_predict_from_factorset(self._handle._h, self._fs, _p(Xtest), m, _p(mean), _p(var)))
+        return mean, var
+
+    def free(self):
+        if self._fs:
+            lib().ccgp_factorset_free(self._handle._h, self._fs)
+            self._fs = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class MultiHandle:
@@ -446,6 +488,21 @@ class Handle:
         self._chk(lib().ccgp_predict_batch(self._h, _p(X), n, d, _p(y), K, _p(params), S, _p(Xtest), m,
                                            float(sigma2), _p(mean), _p(var), _p(beta), _ipt(st)))
         return mean, var, beta, st
+
+    # -- 8(f)-2: device-resident factor set -------------------------------------------------
+    def factor_batch(self, X, y, K, params, sigma2):
+        """Factorise the S draws once and keep the factors on the device -> FactorSet (use as a context manager or
+        call .free()).  .loglik / .beta / .status hold what ccgp_loglik_batch would have returned."""
+        X, y = _f(X), _f(np.ravel(y))
+        n, d = X.shape
+        params = _f(np.atleast_2d(params))
+        S = params.shape[0]
+        ll, beta = np.empty(S), np.empty(S)
+        st = np.zeros(S, dtype=np.int32)
+        fs = c_void_p()
+        self._chk(lib().ccgp_factor_batch(self._h, _p(X), n, d, _p(y), K, _p(params), S, float(sigma2),
+                                          ctypes.byref(fs), _p(ll), _p(beta), _ipt(st)))
+        return FactorSet(self, fs, S, ll, beta, st)
 
     # -- device-resident forms (torch tensors or raw pointers) ----------------------------
     @staticmethod

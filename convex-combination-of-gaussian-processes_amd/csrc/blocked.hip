@@ -45,6 +45,13 @@ struct GemmArgs {
   int ne;    // extra full tile rows below the right-hand-side row (cross-correlation rows)
   int extra_lower;  // 1: the extra rows are the identity (block row te is zero left of block column te)
   int mode;  // 0: update, 1: trsm
+  // prediction from a KEPT factor (ccgp_predict_from_factorset): the extra tile rows live in their own
+  // buffer E (ne x 128 rows, leading dimension lde, e_stride elements per matrix) instead of below the
+  // matrix, and a launch covers ONLY those rows (rows_only): the factor itself is read-only
+  double* E;
+  size_t e_stride;
+  int lde;
+  int rows_only;
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
@@ -381,7 +388,8 @@ constexpr size_t gemm_lds_bytes() {
 // sides (diag_rhs_tile, never split into strips), then the tile rows below the diagonal and the extra
 // tile rows (prediction: r(x_t)'; inverse / gradient: identity), each as S column strips.  trsm (MODE 1):
 // tile rows j+1 .. nt-1, the thin right-hand-side tile row nt, then the extra rows.
-__host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, int ne, int S) {
+__host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, int ne, int S, int rows_only = 0) {
+  if (rows_only) return mode == 0 ? ne * S : ne;
   return mode == 0 ? 1 + ((nt - 1 - j) + ne) * S : (nt - j) + ne;
 }
 
@@ -391,7 +399,7 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   // XCD group (blocks are dealt round-robin over the 8 XCDs, so index % 8 labels the group and
   // all tiles of one matrix share the Q panel in that XCD's L2)
   const int L = blockIdx.x;
-  const int per_grp = 8 * gemm_units_per_matrix(MODE, g.nt, g.j, g.ne, S);
+  const int per_grp = 8 * gemm_units_per_matrix(MODE, g.nt, g.j, g.ne, S, g.rows_only);
   const int grp = L / per_grp, r = L % per_grp;
   const int b = grp * 8 + (r & 7);
   if (b >= g.nb) return;
@@ -399,7 +407,10 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   const int ld = g.ld;
   int u = r >> 3;   // unit index inside the matrix
   int i, strip = 0;
-  if (MODE == 0) {
+  if (g.rows_only) {
+    strip = MODE == 0 ? u % S : 0;
+    i = g.nt + 1 + (MODE == 0 ? u / S : u);
+  } else if (MODE == 0) {
     if (u == 0) {
       diag_rhs_tile(smem, Ab + (size_t)g.j * kTile, Ab + g.npad, ld, g.j * kTile,
                     Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld);
@@ -423,27 +434,35 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
     if (g.j < te || (MODE == 0 && g.j == te)) return;
     k0 = te * kTile;
   }
+  // tile row i: rows i*128.. of the matrix array, or -- extra rows kept in their own buffer -- of E
+  double* rowbase = Ab + (size_t)i * kTile;
+  int rld = ld;
+  if (g.E && i > g.nt) {
+    rowbase = g.E + (size_t)b * g.e_stride + (size_t)(i - g.nt - 1) * kTile;
+    rld = g.lde;
+  }
   const double* P;
   const double* Q;
   int ldP, ldQ, Kdim;
   if (MODE == 0) {
-    P = Ab + (size_t)i * kTile + (size_t)k0 * ld;
+    P = rowbase + (size_t)k0 * rld;
     Q = Ab + (size_t)g.j * kTile + c0 + (size_t)k0 * ld;
-    ldP = ldQ = ld;
+    ldP = rld;
+    ldQ = ld;
     Kdim = g.j * kTile - k0;
   } else {
-    P = Ab + (size_t)i * kTile + (size_t)g.j * kTile * ld;
+    P = rowbase + (size_t)g.j * kTile * rld;
     Q = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile + c0;
-    ldP = ld;
+    ldP = rld;
     ldQ = kTile;
     Kdim = kTile;
   }
-  double* C = Ab + (size_t)i * kTile + ((size_t)g.j * kTile + c0) * ld;
+  double* C = rowbase + ((size_t)g.j * kTile + c0) * rld;
   constexpr bool TRI = MODE == 1 && S == 1;   // trsm: Q is the lower-triangular inverse block
   if constexpr (MODE == 1) {
-    if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE); return; }
+    if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
   }
-  gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, ld, MODE);
+  gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
 }
 
 // distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
@@ -479,7 +498,7 @@ static int pick_strips(int nb8, int tiles) {
 
 static void launch_gemm(hipStream_t s, const GemmArgs& g, int mode, int S) {
   const int nb8 = round_up(g.nb, 8);
-  const dim3 grid(nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S)), block(256);
+  const dim3 grid(nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S, g.rows_only)), block(256);
   if (mode == 0) {
     if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
     else hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
@@ -703,6 +722,9 @@ struct PredFinishArgs {
   const double* A;
   size_t a_stride;
   int npad, ld, n, m;
+  const double* E;   // rows L^-1 r(x_t) when they are kept outside the matrix array (else nullptr)
+  size_t e_stride;
+  int lde;
   const double* s11;
   const double* beta;
   const int* status;
@@ -718,10 +740,11 @@ __global__ __launch_bounds__(256) void predict_finish_kernel(PredFinishArgs g) {
   if (t >= g.m) return;
   const double* Ab = g.A + (size_t)b * g.a_stride;
   const double* zrow = Ab + g.npad;
-  const double* wrow = Ab + g.npad + kTile + t;
+  const double* wrow = g.E ? g.E + (size_t)b * g.e_stride + t : Ab + g.npad + kTile + t;
+  const int ldw = g.E ? g.lde : g.ld;
   double ww = 0.0, z1w = 0.0, zyw = 0.0;
   for (int c = 0; c < g.n; ++c) {
-    const double w = wrow[(size_t)c * g.ld];
+    const double w = wrow[(size_t)c * ldw];
     ww = fma(w, w, ww);
     z1w = fma(zrow[1 + (size_t)c * g.ld], w, z1w);
     zyw = fma(zrow[(size_t)c * g.ld], w, zyw);
@@ -1046,7 +1069,7 @@ struct GroupRun {
       fa.s11_out = w.fin; fa.beta_out = w.fin + nb;
       hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, s, fa);
       if (pr) {
-        PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, pr->m, w.fin, w.fin + nb, status, b0, pr->S,
+        PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, pr->m, nullptr, 0, 0, w.fin, w.fin + nb, status, b0, pr->S,
                           sigma2, pr->mean, pr->var};
         hipLaunchKernelGGL(predict_finish_kernel, dim3((pr->m + 255) / 256, nb), dim3(256), 0, s, pa);
       }
@@ -1111,6 +1134,49 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   // diag / trsm underneath the other half's update (33.9 vs 33.8 ms: the half-size update launches
   // lose to wave quantisation what the overlap gains).
   r.run_all();
+}
+
+// ---- prediction from a kept factor set ----------------------------------------------
+// The factor of every draw stays in HBM exactly as the sweep left it (lower tiles L, inverted diagonal
+// blocks W_j, the rows z_y = L^-1 y and z_1 = L^-1 1, beta, 1'R^-1 1): what Metro caches per accepted draw
+// as R.Inv (HX:515-525) and predict.post reads back (HX:655-665).  A new set of test sites then costs
+// only the forward substitution of its m cross-correlation rows: the SAME update / trsm tile kernels,
+// launched over the extra rows alone (rows_only), so the result is bit-identical to a full
+// ccgp_predict_batch sweep -- same kernels, same k order -- at O(m n^2) instead of O(n^3).
+void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int npad, int S, double* E,
+                                  size_t e_stride, int lde, int m, const int* status, double sigma2,
+                                  double* mean, double* var) {
+  static unsigned long long attr_mask = 0;
+  once_per_device(attr_mask, [] {
+    raise_lds_limit((const void*)chol_update_kernel, "chol_update_kernel");
+    raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
+    raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
+  });
+  const int nt = npad / kTile, ne = lde / kTile;
+  hipStream_t s = h->stream;
+  GemmArgs g{};
+  g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
+  g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = S; g.ld = w.ld; g.ne = ne;
+  g.extra_lower = 0; g.E = E; g.e_stride = e_stride; g.lde = lde; g.rows_only = 1;
+  const int nb8 = round_up(S, 8);
+  for (int j = 0; j < nt; ++j) {
+    g.j = j;
+    if (j > 0) {
+      ScopedTimer t(h, CCGP_T_UPDATE, s);
+      g.mode = 0;
+      // few rows: two half-width strips double the workgroups of a launch that cannot fill the chip
+      launch_gemm(s, g, 0, h->opt_strips > 0 ? h->opt_strips : (nb8 * ne < 256 ? 2 : 1));
+    }
+    {
+      ScopedTimer t(h, CCGP_T_TRSM, s);
+      g.mode = 1;
+      launch_gemm(s, g, 1, 1);
+    }
+  }
+  ScopedTimer t(h, CCGP_T_SOLVE, s);
+  PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, m, E, e_stride, lde, w.fin, w.fin + S, status, 0, S,
+                    sigma2, mean, var};
+  hipLaunchKernelGGL(predict_finish_kernel, dim3((m + 255) / 256, S), dim3(256), 0, s, pa);
 }
 
 }  // namespace ccgp

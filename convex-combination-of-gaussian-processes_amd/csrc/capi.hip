@@ -1009,4 +1009,150 @@ int ccgp_predict_batch(ccgp_handle* h, const double* X, int n, int d, const doub
   return count_bad(st.data(), S);
 }
 
+// ---- 8(f)-2: device-resident factor set --------------------------------------------------------------
+struct ccgp_factorset {
+  int device = 0;
+  int n = 0, d = 0, K = 0, S = 0, npad = 0;
+  double sigma2 = 0.0;
+  ccgp::KernelFamily fam;
+  bool fused = false;      // n <= 128: nothing but the draws is kept (see ccgp_factor_batch)
+  void* mem = nullptr;
+  size_t bytes = 0;
+  double* X = nullptr;     // device copies
+  double* y = nullptr;
+  double* params = nullptr;
+  double* ll = nullptr;
+  double* beta = nullptr;
+  int* status = nullptr;
+  ccgp::BlockedWs w{};
+};
+
+int ccgp_factor_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                      const double* params, int S, double sigma2, ccgp_factorset** out,
+                      double* out_loglik, double* out_beta, int* status) {
+  if (!h) return CCGP_EINVAL;
+  if (bad_shape(n, d, K) || S < 1 || !X || !y || !params || !out)
+    return fail(h, CCGP_EINVAL, "ccgp_factor_batch: bad argument");
+  *out = nullptr;
+  if (int frc = check_family(h, h->fam, d, K)) return frc;
+  CCGP_HIP(hipSetDevice(h->device));
+  const int P = K + K * d;
+  const bool fused = h->fam.id == 0 && n <= kSmallMaxN && small_lds_bytes(n, d, 1) <= (size_t)kLdsBytes - 64;
+  const int npad = round_up(n, kTile);
+  size_t head = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                Carver::al(sizeof(double) * (size_t)S * P) + 2 * Carver::al(sizeof(double) * S) +
+                Carver::al(sizeof(int) * (size_t)S);
+  size_t bytes = head + (fused ? 0 : blocked_ws_bytes(npad, S, 0) + 256);
+  ccgp_factorset* fs = new ccgp_factorset();
+  if (hipMalloc(&fs->mem, bytes) != hipSuccess) {
+    delete fs;
+    return fail(h, CCGP_ENOMEM, "ccgp_factor_batch: " + std::to_string(bytes) + " B for " + std::to_string(S) +
+                                    " factors do not fit on the device");
+  }
+  fs->bytes = bytes; fs->device = h->device; fs->n = n; fs->d = d; fs->K = K; fs->S = S; fs->npad = npad;
+  fs->sigma2 = sigma2; fs->fam = h->fam; fs->fused = fused;
+  Carver c(fs->mem);
+  fs->X = c.take<double>((size_t)n * d);
+  fs->y = c.take<double>(n);
+  fs->params = c.take<double>((size_t)S * P);
+  fs->ll = c.take<double>(S);
+  fs->beta = c.take<double>(S);
+  fs->status = c.take<int>(S);
+  auto bail = [&](int code) {
+    (void)hipFree(fs->mem);
+    delete fs;
+    return code;
+  };
+  if (hipMemcpyAsync(fs->X, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipMemcpyAsync(fs->y, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipMemcpyAsync(fs->params, params, sizeof(double) * (size_t)S * P, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipMemsetAsync(fs->status, 0, sizeof(int) * (size_t)S, h->stream) != hipSuccess)
+    return bail(fail(h, CCGP_EHIP, "ccgp_factor_batch: upload failed"));
+  DrawView dv{fs->params, S, K, d};
+  dv.fam = h->fam;
+  if (fused) {
+    // n <= 128: the factor of a draw lives and dies in registers / LDS inside the fused evaluator (10 us);
+    // storing it would cost more HBM traffic than regenerating it.  The set keeps the draws; likelihood
+    // and beta are evaluated once here, prediction re-runs the fused predictor on the resident inputs.
+    int rc = loglik_dev(h, fs->X, n, d, fs->y, K, fs->params, S, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, fs->ll,
+                        fs->beta, fs->status);
+    if (rc) return bail(rc);
+  } else {
+    fs->w = blocked_carve(c.take<char>(blocked_ws_bytes(npad, S, 0)), npad, S, 0);
+    blocked_loglik(h, fs->X, n, d, fs->y, dv, 0, S, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, fs->w, fs->ll,
+                   fs->beta, fs->status);
+    if (hipGetLastError() != hipSuccess) return bail(fail(h, CCGP_EHIP, "ccgp_factor_batch: launch failed"));
+  }
+  std::vector<int> st(S);
+  hipError_t e = hipSuccess;
+  if (out_loglik) e = hipMemcpyAsync(out_loglik, fs->ll, sizeof(double) * S, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && out_beta)
+    e = hipMemcpyAsync(out_beta, fs->beta, sizeof(double) * S, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(st.data(), fs->status, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return bail(fail(h, CCGP_EHIP, std::string("ccgp_factor_batch: ") + hipGetErrorString(e)));
+  if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)S);
+  *out = fs;
+  return count_bad(st.data(), S);
+}
+
+int ccgp_predict_from_factorset(ccgp_handle* h, const ccgp_factorset* fs, const double* Xtest, int m,
+                                double* out_mean, double* out_var) {
+  if (!h) return CCGP_EINVAL;
+  if (!fs || !Xtest || m < 1 || !out_mean || !out_var)
+    return fail(h, CCGP_EINVAL, "ccgp_predict_from_factorset: bad argument");
+  if (fs->device != h->device)
+    return fail(h, CCGP_EINVAL, "ccgp_predict_from_factorset: the factor set lives on another device");
+  CCGP_HIP(hipSetDevice(h->device));
+  const int n = fs->n, d = fs->d, S = fs->S;
+  size_t need = Carver::al(sizeof(double) * (size_t)m * d) + 2 * Carver::al(sizeof(double) * (size_t)S * m);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dXt = c.take<double>((size_t)m * d);
+  double* dmean = c.take<double>((size_t)S * m);
+  double* dvar = c.take<double>((size_t)S * m);
+  CCGP_HIP(hipMemcpyAsync(dXt, Xtest, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice, h->stream));
+  if (fs->fused) {
+    const ccgp::KernelFamily keep = h->fam;
+    h->fam = fs->fam;
+    rc = ccgp_predict_batch_dev(h, fs->X, n, d, fs->y, fs->K, fs->params, S, dXt, m, fs->sigma2, dmean, dvar,
+                                nullptr, nullptr);
+    h->fam = keep;
+    if (rc) return rc;
+  } else {
+    const int ne = (m + kTile - 1) / kTile, lde = ne * kTile;
+    const size_t e_stride = (size_t)lde * fs->npad;
+    rc = ensure_ws(h, sizeof(double) * e_stride * S);
+    if (rc) return rc;
+    double* E = static_cast<double*>(h->ws);
+    CCGP_HIP(hipMemsetAsync(E, 0, sizeof(double) * e_stride * S, h->stream));
+    DrawView dv{fs->params, S, fs->K, d};
+    dv.fam = fs->fam;
+    {
+      ScopedTimer t(h, CCGP_T_COV);   // rows t = r(x_t)' (Mixed.corr.vec, HX:425-431)
+      launch_cov_cross_batched(h->stream, dXt, m, fs->X, n, d, dv, 0, S, E, e_stride, lde);
+    }
+    blocked_predict_from_factors(h, fs->w, n, fs->npad, S, E, e_stride, lde, m, fs->status, fs->sigma2, dmean, dvar);
+    CCGP_LAUNCH_CHECK();
+  }
+  CCGP_HIP(hipMemcpyAsync(out_mean, dmean, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(out_var, dvar, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  return CCGP_OK;
+}
+
+size_t ccgp_factorset_bytes(const ccgp_factorset* fs) { return fs ? fs->bytes : 0; }
+
+int ccgp_factorset_free(ccgp_handle* h, ccgp_factorset* fs) {
+  if (!fs) return CCGP_OK;
+  if (h) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+  }
+  if (fs->mem) (void)hipFree(fs->mem);
+  delete fs;
+  return CCGP_OK;
+}
+
 }  // extern "C"

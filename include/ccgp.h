@@ -182,6 +182,28 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
                            const double* dparams, int S, const double* dXtest, int m,
                            double sigma2, double* d_mean, double* d_var, double* d_beta,
                            int* d_status);
+/* ---- device-resident factor set ------------------------------------------------
+ * Metro caches R.Inv and beta of every accepted draw (HX:515-525), factors.frame flattens them into a
+ * (5 + 2n + n^2)-column data-frame row (HX:625-644) and predict.post re-parses that row for every test
+ * site (HX:655-665).  Here the per-draw cache stays on the device as the Cholesky factor the sweep left
+ * behind (lower tiles, inverted diagonal blocks, L^-1 y, L^-1 1, beta, 1'R^-1 1): ccgp_factor_batch
+ * factorises S draws ONCE, ccgp_predict_from_factorset then serves any number of test sets at the cost
+ * of their forward substitutions only (O(m n^2) per draw instead of O(n^3)); results are bit-identical to
+ * ccgp_predict_batch.  For n <= 128 the set keeps the draws and the resident inputs only -- the fused
+ * evaluator regenerates a factor in registers faster than it could be read back from HBM.
+ * All S factors must fit on the device together (142 MB each at n = 4096); CCGP_ENOMEM otherwise.
+ * out_loglik / out_beta / status (S each) may be NULL.  The converter that materialises the reference's
+ * wide frame for drop-in callers is rsurface.factors_frame_from_draws. */
+typedef struct ccgp_factorset ccgp_factorset;
+int ccgp_factor_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
+                      const double* params, int S, double sigma2, ccgp_factorset** out,
+                      double* out_loglik, double* out_beta, int* status);
+/* out_mean / out_var: S x m column-major, as ccgp_predict_batch */
+int ccgp_predict_from_factorset(ccgp_handle* h, const ccgp_factorset* fs, const double* Xtest, int m,
+                                double* out_mean, double* out_var);
+size_t ccgp_factorset_bytes(const ccgp_factorset* fs);
+int ccgp_factorset_free(ccgp_handle* h, ccgp_factorset* fs);
+
 /* literal factors(): out = (mean.factor[n], var.factor1[n], var.factor2) */
 int ccgp_factors(ccgp_handle* h, const double* R_inv, double beta, const double* y, int n,
                  double* out);

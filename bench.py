@@ -398,6 +398,19 @@ def main():
         assert full.shape[0] == total and torch.equal(full[lo:hi].to(dev), d_ll), "all-gather mismatch"
     bad = int((d_st != 0).sum().item())
     finite = bool(torch.isfinite(d_ll).all().item())
+    # what was just timed, against CPU potrf + forward solves of the same draws (tests/golden/make_cfg4_digest.py)
+    digest_ok = None
+    if args.workload == "cfg4" and n == 4096 and total <= 512:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "cfg4_loglik_512.json")) as fh:
+                ref = json.load(fh)
+            got_ll, got_b = d_ll.cpu().numpy(), d_beta.cpu().numpy()
+            digest_ok = bool(np.allclose(got_ll, np.array(ref["loglik"])[lo:hi], rtol=1e-9, atol=0.0) and
+                             np.allclose(got_b, np.array(ref["beta"])[lo:hi], rtol=1e-7, atol=1e-10))
+        except FileNotFoundError:
+            digest_ok = None
+        if digest_ok is False:
+            raise SystemExit("bench.py: rank %d log-likelihoods differ from tests/golden/cfg4_loglik_512.json" % rank)
 
     if rank == 0:
         value = total * args.steps / elapsed
@@ -410,7 +423,8 @@ def main():
             "config": {"workload": wl_name, "n": n, "d": d, "K": K, "evals_total": total,
                        "evals_per_gpu": B, "parallelism": "grid sharded over %d GPU(s), one all-gather%s" % (
                            world, " (gloo rehearsal, ranks share devices)" if host_gather else ""),
-                       "failed_evals": bad, "all_finite": finite},
+                       "failed_evals": bad, "all_finite": finite,
+                       "matches_cpu_potrf_digest": digest_ok},
             "kernel_ms_per_step": {k: v[0] for k, v in breakdown.items() if v[1]},
             "kernel_ms_per_step_source": "one extra step with every launch group timed (outside the timed region)",
         }

@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) accs[jj] = 0.0;
   // per component: the d-loop keeps the 16 dot products of this row in registers (one LDS read
-  // of the row coordinate and 16 broadcast reads per dimension instead of two reads per entry)
+  // of the row coordinate and 16 broadcast reads per dimension instead of two reads per entry).
+  // Round 2 tried the dimension loop OUTSIDE a group of three components (column coordinates read once
+  // per group, 3 x 16 dot products in registers: a third of the LDS reads): 179 VGPRs instead of 108, two
+  // waves per SIMD instead of four, and 19.4 instead of 17.2 ms for 512 matrices -- the kernel lives on
+  // occupancy (independent exp chains), not on LDS bandwidth.  Not kept.
   for (int c = 0; c < K; ++c) {
     double sdot[JW];
 #pragma unroll

@@ -173,6 +173,50 @@ def make_gv():
     dump("gv_golden.json", out)
 
 
+def make_gv_all():
+    """Every Ground-Vibrations train/test pair the reference ships (9 of size 50, 8 of size 90 -- BASELINE config 5
+    runs all of them; gv_golden.json above holds sample 1 of each size in full): 4 draws x every 5th test site."""
+    draws = [(0.70, 0.30, 15.0), (0.80, 0.20, 30.0), (0.62, 0.45, 11.0), (0.93, 0.24, 19.0)]
+    out = dict(draws=arr(draws), site_step=5, sets=[])
+    for size, count in ((50, 9), (90, 8)):
+        for i in range(1, count + 1):
+            _, tr = read_table(os.path.join(DATA, "gv", "train_%d_%d.txt" % (size, i)))
+            _, te = read_table(os.path.join(DATA, "gv", "test_%d_%d.txt" % (size, i)))
+            D, y, Dt = tr[:, :9], tr[:, 9], te[::5, :9]
+            s2 = float(np.var(y, ddof=1))
+            mean, var, betas = orc.predict_table(D, y, draws, Dt, s2)
+            out["sets"].append(dict(size=size, sample=i, sigma2=s2, mean=arr(mean), var=arr(var), beta=arr(betas)))
+    dump("gv_all_golden.json", out)
+
+
+def make_cfg3_bundled():
+    """BASELINE config 3 on the grid AS BUNDLED (2D Codes and Designs/hyperpars.matrix.txt was tuned for 14 points;
+    on maximin-100 most of its covariance matrices are numerically singular): for three grid rows, every one of
+    the 1728 Halton nodes -- the conditional log-likelihood where the reference arithmetic succeeds, null where
+    its Cholesky (mnormt::dmnorm -> chol, ADV:573) stops, and the condition number, so that the test can tell
+    a clear failure from a borderline one."""
+    _, X = read_table(os.path.join(DATA, "maximin_100.txt"))
+    _, H = read_table(os.path.join(DATA, "adv_hyperpars_matrix.txt"))
+    y = np.array([orc.test_function_2d(a, b, 4) for a, b in X])
+    s2, N, tau, lam = float(np.var(y, ddof=1)), 1728, 100.0, 4.0
+    u = orc.runif_halton(N)
+    rows = []
+    for g in (0, 29, 59):
+        th1, th2 = orc.qigamma(u, H[g, 0], H[g, 1]), orc.qigamma(u, H[g, 2], H[g, 3])
+        vals, conds = [], []
+        for j in range(N):
+            w = np.array([u[j], 1.0 - u[j]])
+            Th = np.array([[th1[j], th2[j]], [(1 + lam) * th1[j], (1 + lam) * th2[j]]])
+            S = s2 * np.sum(w ** 2) * orc.mixed_corr_matrix_general(X, w, Th) + tau ** 2
+            conds.append(float(np.linalg.cond(S)))
+            try:
+                vals.append(float(orc.loglik_general(X, y, w, Th, s2, orc.MEAN_ZERO_PLUS_TAU2, tau ** 2)[0]))
+            except np.linalg.LinAlgError:
+                vals.append(None)
+        rows.append(dict(row=g, values=vals, cond=conds))
+    dump("cfg3_bundled_golden.json", dict(sigma2=s2, N=N, tau=tau, aniso_lambda=lam, y=arr(y), rows=rows))
+
+
 # ----------------------------------------------------------------------------- 1-D (config 1)
 def make_d1():
     with open(os.path.join(DATA, "d1_designs_head.txt")) as fh:
@@ -213,6 +257,6 @@ def make_d1f():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hx", "ani", "adv", "gv", "d1", "d1f"]
+    which = sys.argv[1:] or ["hx", "ani", "adv", "gv", "gv_all", "cfg3_bundled", "d1", "d1f"]
     for w in which:
         globals()["make_" + w]()

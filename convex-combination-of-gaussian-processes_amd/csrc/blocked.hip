@@ -490,7 +490,7 @@ CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
 // S = 4 never wins any more (the single-workgroup diagonal tile is its long pole) and is gone.
 static int pick_strips(int nb8, int tiles) {
   const long w1 = (long)nb8 * (1 + tiles), w2 = (long)nb8 * (1 + 2 * tiles);
-  if (tiles == 0 || w1 > 2048) return 1;
+  if (tiles == 0 || w1 > 2048 || nb8 > 128) return 1;   // 512-matrix chunks: S = 1 measured faster at every block column
   const double c1 = 16.3 * (double)((w1 + 255) / 256);
   const double c2 = 13.7 + 7.8 * (double)((w2 + 255) / 256 - 1);
   return c2 < c1 ? 2 : 1;

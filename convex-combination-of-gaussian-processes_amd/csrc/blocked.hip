@@ -52,6 +52,12 @@ struct GemmArgs {
   size_t e_stride;
   int lde;
   int rows_only;
+  // update only: the workgroup that has just finished the diagonal tile goes on to factorise and invert it
+  // (diag_factor) while the other tiles of the launch are still being updated
+  int fuse_diag;
+  double* logdet_part;
+  int* status;
+  int n;
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
@@ -207,6 +213,7 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
 #undef CCGP_LOADF
 #undef CCGP_MFMAS
 }
+
 
 // C = C - acc (mode 0) or C = acc (mode 1) for one strip.
 template <int S, bool THIN, bool TRI = false>
@@ -384,129 +391,6 @@ constexpr size_t gemm_lds_bytes() {
   return sizeof(double) * 2 * TileGeom<S, false>::BK * (kTile + kTile / S);   // two unpadded stages
 }
 
-// Workgroups of one launch.  update (MODE 0), per matrix: ONE workgroup for the diagonal tile + right-hand
-// sides (diag_rhs_tile, never split into strips), then the tile rows below the diagonal and the extra
-// tile rows (prediction: r(x_t)'; inverse / gradient: identity), each as S column strips.  trsm (MODE 1):
-// tile rows j+1 .. nt-1, the thin right-hand-side tile row nt, then the extra rows.
-__host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, int ne, int S, int rows_only = 0) {
-  if (rows_only) return mode == 0 ? ne * S : ne;
-  return mode == 0 ? 1 + ((nt - 1 - j) + ne) * S : (nt - j) + ne;
-}
-
-template <int MODE, int S>
-__device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
-  // block index -> (matrix, tile, strip): strips of a tile adjacent, tiles of a matrix on one
-  // XCD group (blocks are dealt round-robin over the 8 XCDs, so index % 8 labels the group and
-  // all tiles of one matrix share the Q panel in that XCD's L2)
-  const int L = blockIdx.x;
-  const int per_grp = 8 * gemm_units_per_matrix(MODE, g.nt, g.j, g.ne, S, g.rows_only);
-  const int grp = L / per_grp, r = L % per_grp;
-  const int b = grp * 8 + (r & 7);
-  if (b >= g.nb) return;
-  double* Ab = g.A + (size_t)b * g.a_stride;
-  const int ld = g.ld;
-  int u = r >> 3;   // unit index inside the matrix
-  int i, strip = 0;
-  if (g.rows_only) {
-    strip = MODE == 0 ? u % S : 0;
-    i = g.nt + 1 + (MODE == 0 ? u / S : u);
-  } else if (MODE == 0) {
-    if (u == 0) {
-      diag_rhs_tile(smem, Ab + (size_t)g.j * kTile, Ab + g.npad, ld, g.j * kTile,
-                    Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld);
-      return;
-    }
-    u -= 1;
-    strip = u % S;
-    i = g.j + 1 + u / S;
-    if (i >= g.nt) i += 1;   // the right-hand-side tile row nt went with the diagonal tile
-  } else {
-    i = g.j + 1 + u;
-  }
-  const bool thin = i == g.nt;
-  const int c0 = strip * (kTile / S);   // first column of this strip inside the tile
-
-  // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
-  // zero (skipped) and the update's k-sum starts at te
-  int k0 = 0;
-  if (g.extra_lower && i > g.nt) {
-    const int te = i - g.nt - 1;
-    if (g.j < te || (MODE == 0 && g.j == te)) return;
-    k0 = te * kTile;
-  }
-  // tile row i: rows i*128.. of the matrix array, or -- extra rows kept in their own buffer -- of E
-  double* rowbase = Ab + (size_t)i * kTile;
-  int rld = ld;
-  if (g.E && i > g.nt) {
-    rowbase = g.E + (size_t)b * g.e_stride + (size_t)(i - g.nt - 1) * kTile;
-    rld = g.lde;
-  }
-  const double* P;
-  const double* Q;
-  int ldP, ldQ, Kdim;
-  if (MODE == 0) {
-    P = rowbase + (size_t)k0 * rld;
-    Q = Ab + (size_t)g.j * kTile + c0 + (size_t)k0 * ld;
-    ldP = rld;
-    ldQ = ld;
-    Kdim = g.j * kTile - k0;
-  } else {
-    P = rowbase + (size_t)g.j * kTile * rld;
-    Q = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile + c0;
-    ldP = rld;
-    ldQ = kTile;
-    Kdim = kTile;
-  }
-  double* C = rowbase + ((size_t)g.j * kTile + c0) * rld;
-  constexpr bool TRI = MODE == 1 && S == 1;   // trsm: Q is the lower-triangular inverse block
-  if constexpr (MODE == 1) {
-    if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
-  }
-  gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
-}
-
-// distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
-#define CCGP_DEFINE_GEMM(NAME, MODE, S, WPS)                                            \
-  __global__ __launch_bounds__(256, WPS) void NAME(GemmArgs g) {                        \
-    extern __shared__ __attribute__((aligned(16))) double smem[];                       \
-    gemm_dispatch<MODE, S>(g, smem);                                                     \
-  }
-CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2)
-CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
-// trsm exists at S = 1 only: it is in place (reads the whole tile row, writes its own columns), so column
-// strips of one tile would race
-CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
-#undef CCGP_DEFINE_GEMM
-
-// Strip count for an update launch.  Measured on MI355X with the round-2 kernels (rocprofv3 per-launch
-// tables, profiles/r02_update_schedule.md): the time of a launch is a step function of its workgroup
-// count in units of 256 (one workgroup per CU; the second workgroup of a CU shares its MFMA pipe, so
-// 256 more workgroups cost as much again):
-//   S = 1:  16.3 us x ceil(W1 / 256)               per 128-deep block of K,  W1 = nb (1 + tiles)
-//   S = 2:  13.7 us + 7.8 us x (ceil(W2 / 256) - 1)                          W2 = nb (1 + 2 tiles)
-// so two half-width strips win when W1 is just above a multiple of 256.  That holds while the launch is
-// small enough for the second read of the row panels to come from L2 / Infinity Cache; beyond ~2000
-// workgroups a strip costs 8.9 us instead of 7.8 and S = 1 always wins (whole 512-matrix chunks).
-// S = 4 never wins any more (the single-workgroup diagonal tile is its long pole) and is gone.
-static int pick_strips(int nb8, int tiles) {
-  const long w1 = (long)nb8 * (1 + tiles), w2 = (long)nb8 * (1 + 2 * tiles);
-  if (tiles == 0 || w1 > 2048 || nb8 > 128) return 1;   // 512-matrix chunks: S = 1 measured faster at every block column
-  const double c1 = 16.3 * (double)((w1 + 255) / 256);
-  const double c2 = 13.7 + 7.8 * (double)((w2 + 255) / 256 - 1);
-  return c2 < c1 ? 2 : 1;
-}
-
-static void launch_gemm(hipStream_t s, const GemmArgs& g, int mode, int S) {
-  const int nb8 = round_up(g.nb, 8);
-  const dim3 grid(nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S, g.rows_only)), block(256);
-  if (mode == 0) {
-    if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
-    else hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
-  } else {
-    hipLaunchKernelGGL(chol_trsm_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
-  }
-}
-
 // ---- diagonal block: Cholesky + inverse in LDS ---------------------------------------------
 struct DiagArgs {
   double* A;
@@ -526,11 +410,12 @@ struct DiagArgs {
 // the same rank-1 sweep that eliminates column k also produces L'^-1 (forward substitution of
 // e_t): per column one barrier, one 256-word column broadcast through LDS, and <= 44 FMAs per
 // thread on registers.  Then L = L' D^1/2 and W = L^-1 = D^-1/2 L'^-1 are written out.
-__global__ __launch_bounds__(256) void diag_kernel(DiagArgs g) {
-  __shared__ double colbuf[2][256];
-  __shared__ double dvec[kTile];
-  __shared__ double red[4];
-  const int b = blockIdx.x;
+// lds: 2 * 256 + 128 + 4 doubles of scratch (kDiagLdsDoubles)
+constexpr int kDiagLdsDoubles = 2 * 256 + kTile + 4;
+__device__ __forceinline__ void diag_factor(const DiagArgs& g, int b, double* lds) {
+  double (*colbuf)[256] = reinterpret_cast<double (*)[256]>(lds);
+  double* dvec = lds + 2 * 256;
+  double* red = dvec + kTile;
   const int tid = threadIdx.x, ty = tid & 15, tx = tid >> 4;
   const int ld = g.ld;
   double* C = g.A + (size_t)b * g.a_stride + (size_t)g.j * kTile + (size_t)g.j * kTile * ld;
@@ -616,6 +501,134 @@ __global__ __launch_bounds__(256) void diag_kernel(DiagArgs g) {
       if (bb >= a) w = c >= r ? I[a][bb] * rs : 0.0;
       W[c + (size_t)r * kTile] = bad ? kNaN : w;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void diag_kernel(DiagArgs g) {
+  __shared__ double lds[kDiagLdsDoubles];
+  diag_factor(g, blockIdx.x, lds);
+}
+
+// Workgroups of one launch.  update (MODE 0), per matrix: ONE workgroup for the diagonal tile + right-hand
+// sides (diag_rhs_tile, never split into strips), then the tile rows below the diagonal and the extra
+// tile rows (prediction: r(x_t)'; inverse / gradient: identity), each as S column strips.  trsm (MODE 1):
+// tile rows j+1 .. nt-1, the thin right-hand-side tile row nt, then the extra rows.
+__host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, int ne, int S, int rows_only = 0) {
+  if (rows_only) return mode == 0 ? ne * S : ne;
+  return mode == 0 ? 1 + ((nt - 1 - j) + ne) * S : (nt - j) + ne;
+}
+
+template <int MODE, int S>
+__device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
+  // block index -> (matrix, tile, strip): strips of a tile adjacent, tiles of a matrix on one
+  // XCD group (blocks are dealt round-robin over the 8 XCDs, so index % 8 labels the group and
+  // all tiles of one matrix share the Q panel in that XCD's L2)
+  const int L = blockIdx.x;
+  const int per_grp = 8 * gemm_units_per_matrix(MODE, g.nt, g.j, g.ne, S, g.rows_only);
+  const int grp = L / per_grp, r = L % per_grp;
+  const int b = grp * 8 + (r & 7);
+  if (b >= g.nb) return;
+  double* Ab = g.A + (size_t)b * g.a_stride;
+  const int ld = g.ld;
+  int u = r >> 3;   // unit index inside the matrix
+  int i, strip = 0;
+  if (g.rows_only) {
+    strip = MODE == 0 ? u % S : 0;
+    i = g.nt + 1 + (MODE == 0 ? u / S : u);
+  } else if (MODE == 0) {
+    if (u == 0) {
+      diag_rhs_tile(smem, Ab + (size_t)g.j * kTile, Ab + g.npad, ld, g.j * kTile,
+                    Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld);
+      if (g.fuse_diag) {
+        // T_jj went to memory through this CU's L1; the waves of the workgroup read it back in diag_factor's
+        // thread layout.  All waves of a workgroup share that L1, so workgroup scope is enough: __syncthreads is
+        // release(workgroup) + s_barrier + acquire(workgroup) -- no L2 write-back, no cache invalidate
+        __syncthreads();
+        DiagArgs dg{g.A, g.a_stride, g.npad, g.invd, g.invd_stride, g.logdet_part, g.status, g.j, g.nt, g.nb, g.n, g.ld};
+        diag_factor(dg, b, smem);   // the staging LDS is free: the K loop ended on a barrier
+      }
+      return;
+    }
+    u -= 1;
+    strip = u % S;
+    i = g.j + 1 + u / S;
+    if (i >= g.nt) i += 1;   // the right-hand-side tile row nt went with the diagonal tile
+  } else {
+    i = g.j + 1 + u;
+  }
+  const bool thin = i == g.nt;
+  const int c0 = strip * (kTile / S);   // first column of this strip inside the tile
+
+  // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
+  // zero (skipped) and the update's k-sum starts at te
+  int k0 = 0;
+  if (g.extra_lower && i > g.nt) {
+    const int te = i - g.nt - 1;
+    if (g.j < te || (MODE == 0 && g.j == te)) return;
+    k0 = te * kTile;
+  }
+  // tile row i: rows i*128.. of the matrix array, or -- extra rows kept in their own buffer -- of E
+  double* rowbase = Ab + (size_t)i * kTile;
+  int rld = ld;
+  if (g.E && i > g.nt) {
+    rowbase = g.E + (size_t)b * g.e_stride + (size_t)(i - g.nt - 1) * kTile;
+    rld = g.lde;
+  }
+  const double* P;
+  const double* Q;
+  int ldP, ldQ, Kdim;
+  if (MODE == 0) {
+    P = rowbase + (size_t)k0 * rld;
+    Q = Ab + (size_t)g.j * kTile + c0 + (size_t)k0 * ld;
+    ldP = rld;
+    ldQ = ld;
+    Kdim = g.j * kTile - k0;
+  } else {
+    P = rowbase + (size_t)g.j * kTile * rld;
+    Q = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile + c0;
+    ldP = rld;
+    ldQ = kTile;
+    Kdim = kTile;
+  }
+  double* C = rowbase + ((size_t)g.j * kTile + c0) * rld;
+  constexpr bool TRI = MODE == 1 && S == 1;   // trsm: Q is the lower-triangular inverse block
+  if constexpr (MODE == 1) {
+    if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
+  }
+  gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
+}
+
+// distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
+#define CCGP_DEFINE_GEMM(NAME, MODE, S, WPS)                                            \
+  __global__ __launch_bounds__(256, WPS) void NAME(GemmArgs g) {                        \
+    extern __shared__ __attribute__((aligned(16))) double smem[];                       \
+    gemm_dispatch<MODE, S>(g, smem);                                                     \
+  }
+CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2)
+CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
+// trsm exists at S = 1 only: it is in place (reads the whole tile row, writes its own columns), so column
+// strips of one tile would race
+CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
+#undef CCGP_DEFINE_GEMM
+
+// Strip count for an update launch.  One workgroup per SIMD-set saturates a CU's four MFMA pipes, so the time of
+// a launch is a step function of its workgroup count in units of 256 (16.3 us per 128-deep block of K and per
+// step; the second resident workgroup of a CU only fills bubbles).  Round 1 cut tiles into column strips to fill
+// the last, partial step; with the diagonal tile as ONE long workgroup (it also factorises the block) half-width
+// strips no longer win anywhere (rocprofv3 per-launch tables, profiles/r02_update_schedule.md sections 3 and 6:
+// best-of per launch 25.57 ms against 25.70 ms at S = 1 for 64 matrices, and S = 1 ahead at every block column
+// for 512).  The S = 2 kernel remains for the rows-only sweeps of ccgp_predict_from_factorset (few, long rows)
+// and as a measurement switch.
+static int pick_strips(int /*nb8*/, int /*tiles*/) { return 1; }
+
+static void launch_gemm(hipStream_t s, const GemmArgs& g, int mode, int S) {
+  const int nb8 = round_up(g.nb, 8);
+  const dim3 grid(nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S, g.rows_only)), block(256);
+  if (mode == 0) {
+    if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
+    else hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
+  } else {
+    hipLaunchKernelGGL(chol_trsm_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
   }
 }
 
@@ -1028,6 +1041,7 @@ struct GroupRun {
     g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
     g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb; g.ld = w.ld; g.ne = w.ne;
     g.extra_lower = job && job->kind >= kJobInverse ? 1 : 0;
+    g.fuse_diag = h->opt_fuse_diag; g.logdet_part = w.z; g.status = status + b0; g.n = n;
     dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;
@@ -1045,7 +1059,7 @@ struct GroupRun {
 
   // L_jj, W_j = L_jj^-1, then L_ij = T_ij W_j' for the rows below
   void panel(int j) {
-    {
+    if (j == 0 || !g.fuse_diag) {   // block column 0 has no update launch; from column 1 on the update's diagonal workgroup does it
       ScopedTimer t(h, CCGP_T_DIAG, s);
       dg.j = j;
       hipLaunchKernelGGL(diag_kernel, dim3(nb), dim3(256), 0, s, dg);

@@ -42,6 +42,7 @@ struct ccgp_handle {
   size_t ws_limit = size_t(24) << 30;   // ccgp_create replaces this by 3/4 of the device's memory
   int opt_strips = 0;                   // CCGP_OPT_UPDATE_STRIPS
   int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
+  int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   // grow-only device scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;

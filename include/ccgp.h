@@ -94,10 +94,12 @@ int ccgp_set_kernel(ccgp_handle* h, int family, double nu);
  * quarters of the device's memory (216 of 288 GB on MI355X), and never more than is free at call time. */
 int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
 /* measurement switches (A/B runs under rocprof; results do not depend on them):
- *   CCGP_OPT_UPDATE_STRIPS  0 = choose per launch (default), 1 | 2 = pin the column-strip count of the
+ *   CCGP_OPT_UPDATE_STRIPS  0 = library's choice (default; S = 1 since round 2), 1 | 2 = pin the column-strip count of the
  *                           blocked Cholesky's trailing-update launches
- *   CCGP_OPT_SMALL_LDS      1 = run n <= 128 on the in-LDS evaluator instead of the register-resident one */
-enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1 };
+ *   CCGP_OPT_SMALL_LDS      1 = run n <= 128 on the in-LDS evaluator instead of the register-resident one
+ *   CCGP_OPT_FUSE_DIAG      1 (default) = the update launch's diagonal-tile workgroup also factorises and inverts
+ *                           the diagonal block; 0 = a separate diag_kernel launch per block column */
+enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2 };
 int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r01j/pmc_traffic.json"   # latest committed rocprofv3 --pmc passes of this bench command
+PMC_TRAFFIC_FILES = ("r02k/pmc_traffic.json", "r02k/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
 
 
 # ----------------------------------------------------------------------------- synthetic inputs
@@ -146,16 +146,16 @@ def update_kernel_flops(n, diag_tiles=True):
 def pmc_traffic(kernel, matrices_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (counters cannot
     be read from inside the process; collected separately exactly as the MI355X guide prescribes).
-    Only quoted when the passes were collected with the same number of matrices per launch."""
-    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-    try:
-        with open(path) as fh:
-            rec = json.load(fh)
-        if rec.get("matrices_per_launch", 64) != matrices_per_launch:
-            return None, None
-        return rec["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/" + PMC_TRAFFIC_FILE
-    except Exception:
-        return None, None
+    Only quoted when a pass was collected with the same number of matrices per launch."""
+    for name in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                rec = json.load(fh)
+            if rec.get("matrices_per_launch", 64) == matrices_per_launch:
+                return rec["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 # ----------------------------------------------------------------------------- CPU baseline

@@ -68,7 +68,11 @@ __device__ __forceinline__ void mat_sync() {
   }
 }
 
-template <int G, int NB, int NE>
+// FULL: n == G * NB exactly (the Heat-Exchanger design: n = 64 = 8 x 8): no padding rows, so the per-entry
+// validity tests (r < n, c < n) and the index clamps disappear.  They compiled to one divergent branch per matrix
+// entry and component (s_and_saveexec / s_cbranch_execz / s_or + hazard s_nops around every exp): ~10 of the
+// ~45 instructions an entry costs in a kernel that is instruction-issue bound.
+template <int G, int NB, int NE, bool FULL = false>
 __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_kernel(RegArgs a) {
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
     for (int aa = bb; aa < NB; ++aa) M[aa][bb] = 0.0;
   int rowi[NB];   // clamped row of every row block (padding rows repeat row n-1; they are overwritten below)
 #pragma unroll
-  for (int aa = 0; aa < NB; ++aa) rowi[aa] = min(ty + G * aa, n - 1);
+  for (int aa = 0; aa < NB; ++aa) rowi[aa] = FULL ? ty + G * aa : min(ty + G * aa, n - 1);
   for (int q = 0; q < K; ++q) {
     const double wq = w2[q];
 #pragma unroll
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
       double sdot[NB][kPair];
 #pragma unroll
       for (int aa = 0; aa < NB; ++aa) sdot[aa][0] = sdot[aa][1] = 0.0;
-      const int c0 = min(tx + G * bb0, n - 1), c1 = min(tx + G * (bb0 + 1), n - 1);
+      const int c0 = FULL ? tx + G * bb0 : min(tx + G * bb0, n - 1);
+      const int c1 = FULL ? tx + G * (bb0 + 1 < NB ? bb0 + 1 : bb0) : min(tx + G * (bb0 + 1), n - 1);
       for (int k = 0; k < d; ++k) {
         // all LDS reads of this dimension first (one round trip), then the arithmetic: left to itself the
         // compiler reuses one register pair for the row coordinates and waits after every single read
@@ -189,7 +194,15 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
 #pragma unroll
         for (int aa = bb; aa < NB; ++aa) {
           const int r = ty + G * aa;
-          if (r < n && c < n && r >= c) {
+          if constexpr (FULL) {
+            // every (r, c) is a matrix entry; entries above the diagonal of the diagonal blocks (aa == bb, ty < tx)
+            // are computed too and zeroed below -- cheaper than a divergent branch
+            const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
+            M[aa][bb] = fma(wq, exp_cov(-dist), M[aa][bb]);
+            // pin the finished entry here: without the branch the compiler sinks the tail of every exp (ldexp + mix)
+            // to the end of the component loop and keeps two temporaries per entry alive until then (580 B of scratch)
+            asm volatile("" : "+v"(M[aa][bb]));
+          } else if (r < n && c < n && r >= c) {
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
             M[aa][bb] = fma(wq, exp_cov(-dist), M[aa][bb]);
           }
@@ -203,14 +216,14 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
 #pragma unroll
     for (int aa = bb; aa < NB; ++aa) {
       const int r = ty + G * aa;
-      if (r < n && c < n) M[aa][bb] = r >= c ? fma(post_scale, M[aa][bb], post_shift) : 0.0;
+      if (FULL || (r < n && c < n)) M[aa][bb] = (aa > bb || r >= c) ? fma(post_scale, M[aa][bb], post_shift) : 0.0;
       else M[aa][bb] = r == c ? 1.0 : 0.0;   // identity on the padding
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const int ridx = ty + G * e;
       double v = 0.0;
-      if (c < n) {
+      if (FULL || c < n) {
         if (ridx == 0) v = a.y[c];
         else if (ridx == 1) v = 1.0;
         else if (NE > 1 && t0 + ridx - 2 < a.m) {
@@ -233,9 +246,10 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
   int bad = 0, cur = 0;
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll 1
     for (int kk = 0; kk < G; ++kk) {
       const int k = G * kb + kk;
-      if (bad || k >= n) break;
+      if (bad || (!FULL && k >= n)) break;
       double* cb = colbuf + cur * (NP + XR);
       if (tx == kk) {
 #pragma unroll
@@ -387,15 +401,23 @@ void launch_one(hipStream_t s, const RegArgs& a) {
   const size_t lds = reg_lds_bytes<G, NB, NE>(a);
   static unsigned long long attr_mask = 0;
   once_per_device(attr_mask, [] {
-    raise_lds_limit((const void*)small_reg_kernel<G, NB, NE>, "small_reg_kernel");
+    raise_lds_limit((const void*)small_reg_kernel<G, NB, NE, false>, "small_reg_kernel");
+    if constexpr (NE == 1) raise_lds_limit((const void*)small_reg_kernel<G, NB, NE, true>, "small_reg_kernel<full>");
   });
+  const bool full = NE == 1 && a.n == G * NB && a.x_stride == 0;
   const int chunks = NE > 1 ? (a.m + (G * NE - 2) - 1) / (G * NE - 2) : 1;
   const int kMaxGrid = 1 << 20;
   RegArgs c = a;
   for (int b0 = 0; b0 < a.B; b0 += kMaxGrid * MPW) {
     c.draw0 = a.draw0 + b0;
     c.B = a.B - b0 < kMaxGrid * MPW ? a.B - b0 : kMaxGrid * MPW;
-    hipLaunchKernelGGL((small_reg_kernel<G, NB, NE>), dim3((c.B + MPW - 1) / MPW, chunks), dim3(256), lds, s, c);
+    if constexpr (NE == 1) {
+      if (full) {
+        hipLaunchKernelGGL((small_reg_kernel<G, NB, NE, true>), dim3((c.B + MPW - 1) / MPW, chunks), dim3(256), lds, s, c);
+        continue;
+      }
+    }
+    hipLaunchKernelGGL((small_reg_kernel<G, NB, NE, false>), dim3((c.B + MPW - 1) / MPW, chunks), dim3(256), lds, s, c);
   }
 }
 

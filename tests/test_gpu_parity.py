@@ -781,3 +781,44 @@ def test_config3_grid_as_bundled(handle):
     P = np.column_stack([u, 1 - u, th1, th2, (1 + lam) * th1, (1 + lam) * th2])
     ll, _, st = handle.loglik_batch(D, y, 2, P, g["sigma2"], 1, g["tau"] ** 2)
     np.testing.assert_array_equal(np.isnan(ll), st != 0)
+
+
+def test_widest_design_and_largest_chunks(handle):
+    """Limits the header admits: d = 64 inputs (the covariance kernel's LDS staging passes the 64 KiB a kernel
+    gets without asking: round-1 advisor finding), and a blocked-path batch of more draws than a grid dimension
+    holds (the chunk index is a grid y / z coordinate: chunks are capped at 65535)."""
+    from ccgp_amd import api
+    rng = np.random.default_rng(3)
+    n, d, K = 70, 64, 2
+    X = rng.random((n, d))
+    y = np.sin(X.sum(axis=1))
+    row = np.concatenate([[0.7, 0.3], rng.uniform(0.01, 0.05, d), rng.uniform(0.3, 0.6, d)])
+    w, Th = orc.unpack_params(row, K, d)
+    R = handle.mixed_corr_matrix(X, K, row)
+    np.testing.assert_allclose(R, orc.mixed_corr_matrix_general(X, w, Th), rtol=1e-12, atol=1e-15)
+    r = handle.mixed_corr_cross(X[:3] + 0.01, X, K, row)
+    want = np.array([orc.mixed_corr_vec_general(x, X, w, Th) for x in X[:3] + 0.01])
+    np.testing.assert_allclose(r, want, rtol=1e-12, atol=1e-15)
+    ll, beta, st = handle.loglik_batch(X, y, K, row[None], 1.0)          # d = 64 does not fit the fused evaluators' LDS budget
+    wl, wb = orc.loglik_general(X, y, w, Th, 1.0)
+    assert st[0] == 0 and ll[0] == pytest.approx(wl, rel=1e-9) and beta[0] == pytest.approx(wb, rel=1e-8)
+    # 70 000 draws of the 1-D Matern family (always the materialised-matrix path): two chunks
+    Xs = np.linspace(0.05, 0.95, 8)[:, None]
+    ys = np.sin(10.0 * Xs[:, 0])
+    B = 70000
+    P = np.column_stack([rng.uniform(0.3, 0.9, B), np.zeros(B), rng.uniform(0.2, 0.6, B), rng.uniform(0.05, 0.15, B)])
+    P[:, 1] = 1.0 - P[:, 0]
+    try:
+        handle.set_kernel(api.KERNEL_MATERN, 5.0)
+        ll, beta, st = handle.loglik_batch(Xs, ys, 2, P, 1.0)
+        pick = np.array([0, 1, 65534, 65535, 65536, B - 1])
+        ll2, beta2, st2 = handle.loglik_batch(Xs, ys, 2, P[pick], 1.0)
+    finally:
+        handle.set_kernel(api.KERNEL_GAUSS, 0.0)
+    assert not st.any() and np.all(np.isfinite(ll))
+    np.testing.assert_array_equal(ll[pick], ll2)
+    np.testing.assert_array_equal(beta[pick], beta2)
+    with pytest.raises(api.CcgpError):
+        handle.set_option(99, 1)
+    with pytest.raises(api.CcgpError):
+        handle.set_option(api.OPT_UPDATE_STRIPS, 3)

@@ -265,6 +265,7 @@ def main():
                     help="cfg4: fixed per-GPU slice instead of a fixed grid (weak scaling; experiments only)")
     ap.add_argument("--strips", type=int, default=0, choices=[0, 1, 2],
                     help="pin the update kernel's column-strip count (ccgp_set_option; 0 = per-launch choice)")
+    ap.add_argument("--no-tail-strips", action="store_true", help="every update tile whole (ccgp_set_option; measurements)")
     ap.add_argument("--no-fuse-diag", action="store_true", help="separate diag_kernel launches (ccgp_set_option; measurements)")
     ap.add_argument("--ws-limit-gib", type=float, default=0.0,
                     help="cap the device scratch (ccgp_set_workspace_limit) to force multi-chunk batches")
@@ -351,6 +352,8 @@ def main():
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.strips:
         h.set_option(api.OPT_UPDATE_STRIPS, args.strips)
+    if args.no_tail_strips:
+        h.set_option(api.OPT_TAIL_STRIPS, 0)
     if args.no_fuse_diag:
         h.set_option(api.OPT_FUSE_DIAG, 0)
     if args.ws_limit_gib > 0:

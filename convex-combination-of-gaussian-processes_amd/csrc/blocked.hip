@@ -55,6 +55,8 @@ struct GemmArgs {
   // update only: the workgroup that has just finished the diagonal tile goes on to factorise and invert it
   // (diag_factor) while the other tiles of the launch are still being updated
   int fuse_diag;
+  int tail_strips;   // host switch (CCGP_OPT_TAIL_STRIPS)
+  int n_s1;   // update, S = 1 kernel: tiles [0, n_s1) (dispatch order) run whole, the rest as two ring-pipelined strips
   double* logdet_part;
   int* status;
   int n;
@@ -215,14 +217,117 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
 }
 
 
+
+// ---- half-width strip with a four-stage ring (tail of an update launch) ---------------------------
+// Same strip geometry, fragments and per-accumulator MFMA order as gemm_accumulate<2, false> (so the same
+// bits), but the LDS holds FOUR stages of 8 k-columns and a stage is requested THREE stages ahead, with counted
+// waits (s_waitcnt vmcnt(6 | 3 | 0): three DMA instructions per wave and stage) instead of a drain.  A strip does
+// half the MFMAs of a full tile per stage, so ALONE on a CU -- which is where the tail strips run -- the
+// one-stage-ahead loop is bound by the latency of its own requests (13.7 us per 128-deep block against 16.3 for
+// a whole tile, profiles/r02_update_schedule.md section 3); for full tiles the same ring was measured and
+// rejected (section 7: they are MFMA-bound even alone).
+__device__ __forceinline__ void strip_accumulate_ring(double* smem, const double* P, int ldP, const double* Q,
+                                                      int ldQ, int Kdim, d4 (&acc)[2][4]) {
+  constexpr int BKd = 8, NST = 4, CW = kTile / 2;
+  constexpr int STAGE = BKd * kTile + BKd * CW;   // doubles: P image [8][128], then Q image [8][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 32;
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // P: wave w stages columns k = w and w + 4 (parity w & 1).  Q: one instruction per wave covers columns
+  // 2w (lanes 0-31) and 2w + 1 (lanes 32-63): parity = lane >> 5
+  const int psrc = ((((lane >> 3) ^ (wave & 1)) << 4) + ((lane & 7) << 1));
+  const double* pP = P + psrc + (size_t)wave * ldP;
+  const int ql = lane & 31, qc = lane >> 5;
+  const int qsrc = ((((ql >> 3) ^ qc) << 4) + ((ql & 7) << 1));
+  const double* pQ = Q + qsrc + (size_t)(2 * wave + qc) * ldQ;
+  auto issue = [&](int slot) {
+    double* Ps_ = smem + slot * STAGE + wave * kTile;
+    double* Qs_ = smem + slot * STAGE + BKd * kTile + wave * 2 * CW;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pP,
+                                     (__attribute__((address_space(3))) void*)Ps_, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pP + (size_t)4 * ldP),
+                                     (__attribute__((address_space(3))) void*)(Ps_ + 4 * kTile), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pQ,
+                                     (__attribute__((address_space(3))) void*)Qs_, 16, 0, 0);
+    pP += (size_t)BKd * ldP;
+    pQ += (size_t)BKd * ldQ;
+  };
+  // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14; expcnt 7 = no wait
+  auto wait_and_meet = [&](int later_stages) {   // wave-uniform: stages requested after the one that must have landed
+    if (later_stages >= 3) __builtin_amdgcn_s_waitcnt(0x0079);        // vmcnt(9) lgkmcnt(0)
+    else if (later_stages == 2) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
+    else if (later_stages == 1) __builtin_amdgcn_s_waitcnt(0x0073);   // vmcnt(3) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+  };
+
+  const int sw = l4 & 1;
+  const int offP = l4 * kTile + l15, offQ = BKd * kTile + l4 * CW + l15;
+  int rbo[4], cbo[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) rbo[t] = (((row0 >> 4) + t) ^ sw) << 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) cbo[t] = (((col0 >> 4) + t) ^ sw) << 4;
+  double pfA[4], qfA[2], pfB[4], qfB[2];
+#define CCGP_RLOADF(PF, QF, SLOT, KK)                                                            \
+  do {                                                                                          \
+    const double* St_ = smem + (SLOT) * STAGE;                                                  \
+    _Pragma("unroll") for (int y = 0; y < 4; ++y) PF[y] = St_[(KK) * 4 * kTile + offP + rbo[y]]; \
+    _Pragma("unroll") for (int x = 0; x < 2; ++x) QF[x] = St_[(KK) * 4 * CW + offQ + cbo[x]];   \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+#define CCGP_RMFMAS(PF, QF, X0, X1)                                                              \
+  do {                                                                                          \
+    _Pragma("unroll") for (int x = (X0); x < (X1); ++x)                                         \
+      _Pragma("unroll") for (int y = 0; y < 4; ++y)                                             \
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(QF[x], PF[y], acc[x][y], 0, 0, 0);   \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+
+  const int nk = Kdim / BKd;
+  const int pre = nk < NST ? nk : NST;
+  for (int t = 0; t < pre; ++t) issue(t);
+  __builtin_amdgcn_sched_barrier(0);
+  wait_and_meet(pre - 1);                               // stage 0 landed; the later ones stay in flight
+  CCGP_RLOADF(pfA, qfA, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int slot = kt & (NST - 1);
+    CCGP_RLOADF(pfB, qfB, slot, 1);
+    CCGP_RMFMAS(pfA, qfA, 0, 2);                        // k-step 0 of stage kt
+    if (kt + 1 < nk) {
+      // stage kt+1 landed for every wave, and stage kt has been read by every wave (its last fragments are in
+      // registers: lgkmcnt(0)), so its slot takes stage kt+4
+      const int last_issued = kt + NST - 1 < nk - 1 ? kt + NST - 1 : nk - 1;
+      wait_and_meet(last_issued - (kt + 1));
+      if (kt + NST < nk) issue(slot);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    CCGP_RMFMAS(pfB, qfB, 0, 1);                        // k-step 1 of stage kt, from registers
+    if (kt + 1 < nk) CCGP_RLOADF(pfA, qfA, (kt + 1) & (NST - 1), 0);
+    CCGP_RMFMAS(pfB, qfB, 1, 2);
+  }
+#undef CCGP_RLOADF
+#undef CCGP_RMFMAS
+}
+
 // C = C - acc (mode 0) or C = acc (mode 1) for one strip.
-template <int S, bool THIN, bool TRI = false>
+template <int S, bool THIN, bool TRI = false, bool RING = false>
 __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
                                           int ldQ, int Kdim, double* C, int ld, int mode) {
   constexpr int NX = TileGeom<S, THIN>::NX;
   constexpr int NY = TileGeom<S, THIN>::NY;
   d4 acc[NX][NY];
-  gemm_accumulate<S, THIN, TRI>(smem, P, ldP, Q, ldQ, Kdim, acc);
+  if constexpr (RING) {
+    static_assert(S == 2 && !THIN && !TRI, "the four-stage ring exists for half-width update strips");
+    strip_accumulate_ring(smem, P, ldP, Q, ldQ, Kdim, acc);
+  } else {
+    gemm_accumulate<S, THIN, TRI>(smem, P, ldP, Q, ldQ, Kdim, acc);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = TileGeom<S, THIN>::row0(wave), col0 = TileGeom<S, THIN>::col0(wave);
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -509,10 +614,17 @@ __global__ __launch_bounds__(256) void diag_kernel(DiagArgs g) {
   diag_factor(g, blockIdx.x, lds);
 }
 
-// Workgroups of one launch.  update (MODE 0), per matrix: ONE workgroup for the diagonal tile + right-hand
-// sides (diag_rhs_tile, never split into strips), then the tile rows below the diagonal and the extra
-// tile rows (prediction: r(x_t)'; inverse / gradient: identity), each as S column strips.  trsm (MODE 1):
-// tile rows j+1 .. nt-1, the thin right-hand-side tile row nt, then the extra rows.
+// Workgroups of one launch.
+// update (MODE 0): first ONE workgroup per matrix for the diagonal tile + right-hand sides (diag_rhs_tile; it goes
+// on to factorise the block, so it is dispatched first), then the tile rows below the diagonal and the extra tile
+// rows (prediction: r(x_t)'; inverse / gradient: identity), matrices in groups of eight, each tile as S column
+// strips.  In the S = 1 kernel the LAST `tail` tiles (in that order) may run as two half-width ring-pipelined
+// strips each: the last, partial step of 256 workgroups then consists of strips only and takes about half a
+// tile time (update_tail()).
+// trsm (MODE 1): per matrix tile rows j+1 .. nt-1, the thin right-hand-side tile row nt, then the extra rows.
+// rows_only (kept factor): the extra rows alone.
+// Block index % 8 = matrix % 8 everywhere: blocks are dealt round-robin over the 8 XCDs, so all tiles of one matrix
+// share the column panel in that XCD's L2.
 __host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, int ne, int S, int rows_only = 0) {
   if (rows_only) return mode == 0 ? ne * S : ne;
   return mode == 0 ? 1 + ((nt - 1 - j) + ne) * S : (nt - j) + ne;
@@ -520,23 +632,16 @@ __host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, in
 
 template <int MODE, int S>
 __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
-  // block index -> (matrix, tile, strip): strips of a tile adjacent, tiles of a matrix on one
-  // XCD group (blocks are dealt round-robin over the 8 XCDs, so index % 8 labels the group and
-  // all tiles of one matrix share the Q panel in that XCD's L2)
   const int L = blockIdx.x;
-  const int per_grp = 8 * gemm_units_per_matrix(MODE, g.nt, g.j, g.ne, S, g.rows_only);
-  const int grp = L / per_grp, r = L % per_grp;
-  const int b = grp * 8 + (r & 7);
-  if (b >= g.nb) return;
-  double* Ab = g.A + (size_t)b * g.a_stride;
   const int ld = g.ld;
-  int u = r >> 3;   // unit index inside the matrix
-  int i, strip = 0;
-  if (g.rows_only) {
-    strip = MODE == 0 ? u % S : 0;
-    i = g.nt + 1 + (MODE == 0 ? u / S : u);
-  } else if (MODE == 0) {
-    if (u == 0) {
+  int b, i, strip = 0;
+  bool ring = false;
+  if (MODE == 0 && !g.rows_only) {
+    const int nb8 = (g.nb + 7) & ~7;
+    if (L < nb8) {
+      b = L;
+      if (b >= g.nb) return;
+      double* Ab = g.A + (size_t)b * g.a_stride;
       diag_rhs_tile(smem, Ab + (size_t)g.j * kTile, Ab + g.npad, ld, g.j * kTile,
                     Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld);
       if (g.fuse_diag) {
@@ -549,15 +654,44 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
       }
       return;
     }
-    u -= 1;
-    strip = u % S;
-    i = g.j + 1 + u / S;
+    const int nfull = (g.nt - 1 - g.j) + g.ne;          // tiles per matrix
+    const int Lt = L - nb8;
+    int u1;                                             // tile index in (group, tile, matrix-in-group) order
+    if (S == 1) {
+      if (Lt >= g.n_s1) {                               // tail: q = 16 a + 8 strip + m  ->  tile n_s1 + 8 a + m
+        const int q = Lt - g.n_s1;
+        u1 = g.n_s1 + ((q >> 4) << 3) + (q & 7);
+        strip = (q >> 3) & 1;
+        ring = true;
+      } else {
+        u1 = Lt;
+      }
+    } else {                                            // every tile as S strips: q = 8 S a + 8 strip + m
+      u1 = ((Lt / (8 * S)) << 3) + (Lt & 7);
+      strip = (Lt >> 3) % S;
+    }
+    const int per_grp = 8 * nfull;
+    const int grp = u1 / per_grp, r = u1 % per_grp;
+    b = grp * 8 + (r & 7);
+    if (b >= g.nb) return;
+    i = g.j + 1 + (r >> 3);
     if (i >= g.nt) i += 1;   // the right-hand-side tile row nt went with the diagonal tile
   } else {
-    i = g.j + 1 + u;
+    const int per_grp = 8 * gemm_units_per_matrix(MODE, g.nt, g.j, g.ne, S, g.rows_only);
+    const int grp = L / per_grp, r = L % per_grp;
+    b = grp * 8 + (r & 7);
+    if (b >= g.nb) return;
+    const int u = r >> 3;   // unit index inside the matrix
+    if (g.rows_only) {
+      strip = MODE == 0 ? u % S : 0;
+      i = g.nt + 1 + (MODE == 0 ? u / S : u);
+    } else {
+      i = g.j + 1 + u;
+    }
   }
+  double* Ab = g.A + (size_t)b * g.a_stride;
   const bool thin = i == g.nt;
-  const int c0 = strip * (kTile / S);   // first column of this strip inside the tile
+  const int c0 = strip * (ring ? kTile / 2 : kTile / S);   // first column of this strip inside the tile
 
   // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
   // zero (skipped) and the update's k-sum starts at te
@@ -595,6 +729,9 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   if constexpr (MODE == 1) {
     if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
   }
+  if constexpr (MODE == 0 && S == 1) {
+    if (ring) { gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
+  }
   gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
 }
 
@@ -621,9 +758,30 @@ CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
 // and as a measurement switch.
 static int pick_strips(int /*nb8*/, int /*tiles*/) { return 1; }
 
-static void launch_gemm(hipStream_t s, const GemmArgs& g, int mode, int S) {
+// Tiles of an update launch that should run as strips: the launch is W1 = nb8 (1 + tiles) workgroups at S = 1 and
+// takes ceil(W1 / 256) steps (one workgroup per CU saturates its MFMA pipes).  If the last step holds `rem` <= 128
+// TILES (the diagonal workgroups are dispatched first and are never in it unless the whole launch is one step),
+// running those tiles as 2 rem ring-pipelined half-width strips on otherwise idle CUs cuts that step to about half.
+static int update_tail(int nb8, int tiles) {
+  const long w1 = (long)nb8 * (1 + tiles), all_tiles = (long)nb8 * tiles;
+  const long rem = w1 % 256;
+  if (rem == 0 || all_tiles == 0) return 0;
+  long tail = rem < all_tiles ? rem : all_tiles;
+  if (rem + tail > 256) return 0;                    // the strips would not fit the same step
+  if (tail != rem && w1 > 256) return 0;             // whole tiles left in the last step: nothing gained
+  return (int)tail;                                  // a multiple of 8 (nb8 is)
+}
+
+static void launch_gemm(hipStream_t s, GemmArgs g, int mode, int S) {
   const int nb8 = round_up(g.nb, 8);
-  const dim3 grid(nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S, g.rows_only)), block(256);
+  int units = nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S, g.rows_only);
+  if (mode == 0 && !g.rows_only) {
+    const int tiles = (g.nt - 1 - g.j) + g.ne;
+    const int tail = (S == 1 && g.tail_strips) ? update_tail(nb8, tiles) : 0;
+    g.n_s1 = nb8 * tiles - tail;
+    units = nb8 + (S == 1 ? g.n_s1 + 2 * tail : nb8 * tiles * S);
+  }
+  const dim3 grid(units), block(256);
   if (mode == 0) {
     if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
     else hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
@@ -1041,7 +1199,7 @@ struct GroupRun {
     g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
     g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb; g.ld = w.ld; g.ne = w.ne;
     g.extra_lower = job && job->kind >= kJobInverse ? 1 : 0;
-    g.fuse_diag = h->opt_fuse_diag; g.logdet_part = w.z; g.status = status + b0; g.n = n;
+    g.fuse_diag = h->opt_fuse_diag; g.tail_strips = h->opt_tail_strips; g.logdet_part = w.z; g.status = status + b0; g.n = n;
     dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;

@@ -344,6 +344,10 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) {
     h->opt_small_lds = value;
     return CCGP_OK;
   }
+  if (option == CCGP_OPT_TAIL_STRIPS && (value == 0 || value == 1)) {
+    h->opt_tail_strips = value;
+    return CCGP_OK;
+  }
   if (option == CCGP_OPT_FUSE_DIAG && (value == 0 || value == 1)) {
     h->opt_fuse_diag = value;
     return CCGP_OK;

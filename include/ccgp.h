@@ -98,8 +98,10 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           blocked Cholesky's trailing-update launches
  *   CCGP_OPT_SMALL_LDS      1 = run n <= 128 on the in-LDS evaluator instead of the register-resident one
  *   CCGP_OPT_FUSE_DIAG      1 (default) = the update launch's diagonal-tile workgroup also factorises and inverts
- *                           the diagonal block; 0 = a separate diag_kernel launch per block column */
-enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2 };
+ *                           the diagonal block; 0 = a separate diag_kernel launch per block column
+ *   CCGP_OPT_TAIL_STRIPS    1 (default) = the tiles of an update launch's last, partial step of 256 workgroups run
+ *                           as two half-width strips each; 0 = every tile whole */
+enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3 };
 int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r02k/pmc_traffic.json", "r02k/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
+PMC_TRAFFIC_FILES = ("r02n/pmc_traffic.json", "r02n/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
 
 
 # ----------------------------------------------------------------------------- synthetic inputs

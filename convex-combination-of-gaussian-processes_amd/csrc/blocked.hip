@@ -1,22 +1,26 @@
 // Batched blocked Cholesky + solves for n > 128 (BASELINE config 4: n = 4096).
 //
-// LEFT-looking, 128-wide block columns, many matrices per launch.  For block column j:
+// LEFT-looking, 128-wide block columns, all matrices of a chunk in one launch per phase.  For block column j:
 //   update : T_ij = A_ij - sum_{k<j} L_ik L_jk'      all tiles i >= j   (f64 MFMA GEMM)
-//   diag   : L_jj = chol(T_jj), W_j = L_jj^-1        one workgroup per matrix, in LDS
+//            + for i = j, in the same workgroup: the right-hand-side rows, then L_jj = chol(T_jj), W_j = L_jj^-1
 //   trsm   : L_ij = T_ij W_j'                        tiles i > j        (f64 MFMA GEMM)
-// The right-hand sides [y 1] ride along as an EXTRA (thin) tile row appended below the
-// matrix (rows npad .. npad+127 of an (npad+128) x npad array, two of them used): update
-// and trsm treat it like any other tile row, so when the sweep ends it holds
-// Z' = [y 1]' L^-T, i.e. the forward substitution L z = b is done -- no separate solve
-// pass over the 4n^2 B factor.  A last tiny kernel turns Z and the pivots into what the
-// reference's dmnorm / beta.MLE return (HX:458-460, HX:570).  Left-looking because every tile is then
-// WRITTEN once (the right-looking form rewrites the whole trailing matrix per block column).  The reads
-// stay: tile (i, j) streams its own row panel L_i,0..j-1 from HBM and shares the column panel L_j,0..j-1
-// with the other tiles of its matrix through that XCD's L2, so the algorithmic read traffic is
-// sum_j (nt - j) j 128 KiB = 0.7 GB per n = 4096 matrix (~ 8 n^3 / (6 nb) B), 1.4 GB per launch of 64
-// matrices at mid sweep; measured 2.4 GB per launch with strips (PMC, profiles/r01j/pmc_traffic.json).
-// At 128-wide tiles that is 16 flop per HBM byte against a machine balance of ~10: MFMA-bound, with
-// HBM at a third of its peak.
+// The right-hand sides [y 1] are rows npad, npad+1 of an (npad+128) x npad array per matrix: the update treats
+// them with the diagonal tile (diag_rhs_tile), trsm as a thin tile row, so when the sweep ends they hold
+// Z' = [y 1]' L^-T, i.e. the forward substitution L z = b is done -- no separate solve pass over the 4n^2 B
+// factor.  A last tiny kernel turns Z and the pivots into what the reference's dmnorm / beta.MLE return
+// (HX:458-460, HX:570).  Left-looking because every tile is then WRITTEN once (the right-looking form rewrites
+// the whole trailing matrix per block column).  The reads stay: tile (i, j) streams its own row panel
+// L_i,0..j-1 from HBM and shares the column panel L_j,0..j-1 with the other tiles of its matrix through that
+// XCD's L2, so the algorithmic traffic is sum_j (nt - j) (j 128 KiB + 256 KiB) = 0.85 GB per n = 4096 matrix,
+// 1.75 GB per launch of 64 matrices averaged over the sweep; measured 1.93 GB (PMC, profiles/r02n/pmc_traffic64.json).
+// At 128-wide tiles that is 16 flop per HBM byte against a machine balance of ~10: MFMA-bound, with HBM at a
+// third of its peak.
+//
+// Schedule of an update launch (profiles/r02_update_schedule.md): a launch of W workgroups takes ceil(W / 256)
+// steps -- one workgroup per CU (one wave per SIMD) already keeps the four MFMA pipes 84 % busy, the second resident
+// workgroup only fills bubbles.  The diagonal workgroups (one per matrix: lower triangle + right-hand sides, then the
+// block factorisation) are dispatched first; whole tiles follow; the <= 128 tiles of a partial last step run as two
+// ring-pipelined half-width strips each.
 //
 // MFMA: v_mfma_f64_16x16x4_f64.  Operand lane map (one f64 per lane):
 //   A[i = lane&15][k = lane>>4],  B[k = lane>>4][j = lane&15],
@@ -64,12 +68,11 @@ struct GemmArgs {
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
 // (128 / S) columns per workgroup, K-loop over 16-deep double-buffered LDS stages.
-//   S = 1: 2 x 2 waves of 64 x 64      S = 2: 2 x 2 waves of 64 x 32      S = 4: 4 x 1 waves of 32 x 32
-// S > 1 exists for wave quantisation: a launch whose workgroup count is 512 m + (a few) would
-// leave the chip mostly idle for a whole tile time; cutting every tile into S column strips
-// shortens that tail S-fold at the price of re-reading the P panel S times through L2.
-// THIN = the right-hand-side tile row: only its first 16 rows carry data, so the waves split
-// the strip's columns between them (16 rows x 32 / 16 / 16 columns per wave for S = 1 / 2 / 4).
+//   S = 1: 2 x 2 waves of 64 x 64      S = 2: 2 x 2 waves of 64 x 32
+// S = 2 re-reads the P panel twice through L2; it serves the rows-only sweeps of a kept factor (few, long rows)
+// and, in its ring-pipelined form (strip_accumulate_ring), the partial last step of an update launch.
+// THIN = trsm's right-hand-side tile row: only its first 16 rows carry data, so the waves split
+// the strip's columns between them (16 rows x 32 columns per wave at S = 1).
 //
 // Staging is LDS-DMA: the next stage is filled by global_load_lds (16 B per lane, one
 // wave-instruction = 1 KiB landing linearly in LDS) while the MFMAs of the current stage run,
@@ -83,7 +86,7 @@ struct TileGeom {
   static constexpr int CW = kTile / S;                                       // columns per workgroup
   static constexpr int NX = THIN ? (S == 1 ? 2 : 1) : (S == 1 ? 4 : 2);      // 16-wide column sub-tiles per wave
   static constexpr int NY = THIN ? 1 : (S == 4 ? 2 : 4);                     // 16-high row sub-tiles per wave
-  static constexpr int BK = 16;   // k-depth of one LDS stage (32 was measured 3 % slower at S = 4)
+  static constexpr int BK = 16;   // k-depth of one LDS stage (32 was measured 3 % slower in round 1)
   __device__ static int row0(int wave) { return THIN ? 0 : (S == 4 ? wave * 32 : (wave >> 1) * 64); }
   __device__ static int col0(int wave) {
     return THIN ? wave * NX * 16 : (S == 4 ? 0 : (wave & 1) * (S == 1 ? 64 : 32));

@@ -61,3 +61,23 @@ def test_errors_come_back_with_the_shard_message(multi):
     D, y, _, _ = load_qian()
     with pytest.raises(api.CcgpError):
         multi.loglik_batch(D, y, 2, np.ones((4, 10)), 1.0, mean_mode=7)
+
+
+def test_kernel_family_reaches_every_shard(handle, multi):
+    """ccgp_multi_set_kernel: the 1-D script's Matern family on every shard's handle."""
+    from ccgp_amd import api
+    X = np.linspace(0.05, 0.95, 8)[:, None]
+    y = np.sin(10.0 * X[:, 0])
+    P = np.array([[0.6 + 0.03 * b, 0.4 - 0.03 * b, 0.3 + 0.02 * b, 0.08 + 0.005 * b] for b in range(7)])
+    try:
+        handle.set_kernel(api.KERNEL_MATERN, 5.0)
+        multi.set_kernel(api.KERNEL_MATERN, 5.0)
+        a = handle.loglik_batch(X, y, 2, P, 1.0)
+        b = multi.loglik_batch(X, y, 2, P, 1.0)
+    finally:
+        handle.set_kernel(api.KERNEL_GAUSS, 0.0)
+        multi.set_kernel(api.KERNEL_GAUSS, 0.0)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    g = handle.loglik_batch(X, y, 2, P, 1.0)          # back on the Gaussian family the values differ
+    assert not np.allclose(g[0], a[0])

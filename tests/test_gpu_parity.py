@@ -743,6 +743,11 @@ def test_multi_chunk_batch_at_n4096_equals_one_pass(handle):
     np.testing.assert_array_equal(ll0, ll1)
     np.testing.assert_array_equal(b0, b1)
     np.testing.assert_array_equal(st0, st1)
+    # an evaluation does not depend on the batch it travels in (8 and 20 matrices take different launch shapes:
+    # whole tiles vs tail strips), which is what makes results identical at 1, 2, 4, 8 ranks
+    ll2, b2, _ = handle.loglik_batch(X, y, K, P[:8], 1.0)
+    np.testing.assert_array_equal(ll2, ll0[:8])
+    np.testing.assert_array_equal(b2, b0[:8])
 
 
 def test_config3_grid_as_bundled(handle):

@@ -106,3 +106,64 @@ def test_hx_hard_coded_hyperprior_pair_is_the_grid_winner_on_the_cpu():
         assert ranking(62.0, start)[0] == 292
     order = ranking(float(np.var(y, ddof=1)), 1)
     assert order[0] == 56 and int(np.where(order == 292)[0][0]) + 1 == 374
+
+
+class _CpuGP:
+    """The CombinedGP("GV") surface fit.py needs, on the compiled CPU evaluator instead of the device (tests only)."""
+    script = "GV"
+    h = None
+
+    @staticmethod
+    def draws_to_params(D_train, draws):
+        d = np.asarray(D_train).shape[1]
+        return np.array([orc.params_from_iso(p, t1, t2, d) for p, t1, t2 in np.atleast_2d(draws)])
+
+    def prediction_table(self, D_test, draws, D_train, sigma2, y_train):
+        from oracle.cpu_baseline import loader as cpu
+        mean, var = cpu.predict_batch(D_train, y_train, 2, self.draws_to_params(D_train, draws), D_test, sigma2)
+        return dict(mean=mean, var=var, y_hat=mean.mean(axis=0))
+
+
+def test_recorded_combined_columns_on_the_cpu():
+    """The Combined-GP columns of the recorded run (one unseeded MCMC + rnorm realisation), per test point, against
+    the host inference layer (fit.py: laplace, Metro, prediction -- HX:483-540, 686-703) driven by the CPU evaluator
+    with sigma2 = the recovered mlegp value: the device-free twin of
+    test_reference_pins_gpu.py::test_ground_vibrations_combined_columns_per_test_point (same bounds, 8 seeds)."""
+    from ccgp_amd import fit
+    from oracle.cpu_baseline import loader as cpu
+    fx = golden("gv_mlegp_recovered.json")
+    rec, Dt = recorded_table()
+    D, y, _, yt = load_gv(50)
+    gp = _CpuGP()
+
+    def logpost_fn(rows):
+        rows = np.atleast_2d(rows)
+        ll, beta, st = cpu.loglik_batch(D, y, 2, gp.draws_to_params(D, fit.transformed_to_draws(rows)), fx["sigma2"],
+                                        threads=1)
+        ll = np.where(st == 0, ll, np.nan)
+        return ll + fit.log_jacobian(rows) + fit.log_prior(rows, "GV"), beta
+
+    S = 8
+    tabs = []
+    for s in range(S):
+        rng = np.random.default_rng(7000 + s)
+        chain = fit.Metro(gp, [1.0, 1.0, 0.0], 5000, 1000, 20, 0.5, D, fx["sigma2"], y, rng=rng, logpost_fn=logpost_fn)
+        draws = fit.transformed_to_draws(chain["sample"])
+        tabs.append(fit.compare_GP(gp, Dt, 0.05, yt, draws, D, fx["sigma2"], y, rng))
+    Y = np.array([t["y_hat"] for t in tabs])
+    yr = rec["y.hat.Combined"]
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a))))
+    rmspe_rec = rms(yr - yt)
+    per_seed = np.array([rms(Y[s] - yr) for s in range(S)])
+    assert per_seed.max() <= 0.06 * rmspe_rec and min(np.corrcoef(Y[s], yr)[0, 1] for s in range(S)) > 0.9995, per_seed
+    Yb = Y.mean(axis=0)
+    U, sv, Vt = np.linalg.svd(Y - Yb, full_matrices=False)
+    dev = yr - Yb
+    resid = dev - Vt[:2].T @ (Vt[:2] @ dev)
+    assert rms(resid) <= 5e-3, rms(resid)          # 8 seeds span the two Monte-Carlo directions less well than 16
+    W = np.array([t["UL"] - t["LL"] for t in tabs])
+    wr = rec["UL.Combined"] - rec["LL.Combined"]
+    assert np.all(np.abs(W.mean(axis=1) / wr.mean() - 1.0) < 0.02)
+    for t in tabs:
+        s = fit.comparison_summary(t)
+        assert abs(s["rmspe"] - rmspe_rec) < 0.03 and s["coverage"] >= 0.93

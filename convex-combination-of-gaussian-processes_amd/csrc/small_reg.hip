@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
       if (tx <= kk) lc[kb] = 0.0;   // columns <= k are finished
 #pragma unroll
       for (int aa = kb; aa < NB; ++aa) lr[aa] = cb[ty + G * aa];
-      if (ty <= kk) lr[kb] = 0.0;   // rows <= k are finished
+      // rows <= k of the diagonal block are NOT masked: lr[kb] only reaches M[kb][kb], and there a row r <= k
+      // meets either a finished column (protected by the lc mask above) or a column c > k >= r, i.e. an entry above
+      // the diagonal that nothing reads.  Three instructions per column less in an issue-bound kernel.
       double le[NE];
 #pragma unroll
       for (int e = 0; e < NE; ++e) le[e] = cb[NP + ty + G * e];

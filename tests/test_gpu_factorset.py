@@ -72,3 +72,23 @@ def test_failed_draw_is_nan_in_every_table(handle):
         assert fs.status[0] != 0 and np.isnan(fs.loglik[0])
         m, v = fs.predict(np.array([[0.3, 0.3], [0.6, 0.1]]))
         assert np.isnan(m).all() and np.isnan(v).all()
+
+
+def test_matern_family_factor_set(handle):
+    """The 1-D script's Matern family always takes the materialised-matrix path: a factor set works there too
+    (n = 8 -> one 128 x 128 tile), with the family captured at factorisation time."""
+    from ccgp_amd import api
+    X = np.linspace(0.05, 0.95, 8)[:, None]
+    y = np.sin(10.0 * X[:, 0])
+    P = np.array([[0.6, 0.4, 0.3, 0.08], [0.75, 0.25, 0.4, 0.12], [0.5, 0.5, 0.25, 0.1]])
+    sites = np.linspace(0.0, 1.0, 140)[:, None]                      # two extra tile rows
+    try:
+        handle.set_kernel(api.KERNEL_MATERN, 5.0)
+        want = handle.predict_batch(X, y, 2, P, sites, 0.7)
+        fs = handle.factor_batch(X, y, 2, P, 0.7)
+    finally:
+        handle.set_kernel(api.KERNEL_GAUSS, 0.0)
+    with fs:
+        got = fs.predict(sites)                                       # the handle is back on the Gaussian family
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])

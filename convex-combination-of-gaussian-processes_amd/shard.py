@@ -35,32 +35,99 @@ def gather_device(backend, tensor_device):
     return tensor_device
 
 
+class RowGatherer:
+    """The one collective of the path, with every buffer allocated ONCE: rank r contributes `sizes[r]` rows of a
+    [*lead, rows, *tail] array (the sharded dimension sits behind `lead`) and every rank receives all `total` rows in
+    rank order.
+
+    One `all_gather_into_tensor` (RCCL all-gather over xGMI when the backend is "nccl") of equal-size padded slots;
+    `gather` only copies: local rows -> this rank's send slot (skipped when the caller computed straight into
+    `self.send`), then the received slots -> the contiguous result (`self.full`, overwritten by the next call).
+    Nothing is allocated, concatenated or synchronised per call, so the collective can sit inside a timed step
+    (round-2 review: the list-of-tensors all_gather + torch.cat did).
+
+    lead = (): the likelihood vectors (rows = evaluations).  lead = (2 M,): the column-major (draw x test site)
+    mean / variance tables of BASELINE config 5 -- a device table S_local x m column-major IS a row-major
+    [m, S_local] block, so the draws are the LAST dimension there."""
+
+    def __init__(self, total, tail=(), dtype=None, device=None, group=None, lead=()):
+        import torch
+        import torch.distributed as dist
+
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.total = int(total)
+        self.sizes = shard_sizes(self.total, self.world)
+        self.offsets = [shard_bounds(self.total, r, self.world)[0] for r in range(self.world)]
+        self.tail = tuple(int(t) for t in tail)
+        self.lead = tuple(int(t) for t in lead)
+        dtype = dtype or torch.float64
+        device = torch.device(device) if device is not None else torch.device("cpu")
+        self.device = device
+        mx = max(self.sizes) if self.sizes else 0
+        self.slot = mx
+        self.even = all(s == mx for s in self.sizes)
+        self.send = torch.zeros(self.lead + (mx,) + self.tail, dtype=dtype, device=device)
+        self.recv = torch.empty((self.world,) + self.lead + (mx,) + self.tail, dtype=dtype, device=device)
+        # evenly divisible and nothing in front of the sharded dimension: the receive buffer IS the result
+        if self.even and not self.lead:
+            self.full = self.recv.view((self.total,) + self.tail)
+        else:
+            self.full = torch.empty(self.lead + (self.total,) + self.tail, dtype=dtype, device=device)
+        self._ax = len(self.lead)
+
+    def _rows(self, t, lo, hi):
+        return t[(slice(None),) * self._ax + (slice(lo, hi),)]
+
+    def gather(self, local=None):
+        """local: tensor [*lead, sizes[rank], *tail] on self.device, or None when the caller has already written its
+        rows into self.send.  Returns self.full ([*lead, total, *tail])."""
+        import torch.distributed as dist
+
+        n_local = self.sizes[self.rank]
+        if local is not None and n_local:
+            self._rows(self.send, 0, n_local).copy_(local, non_blocking=True)
+        if self.world == 1:
+            if self.full.data_ptr() != self.recv.data_ptr():
+                self.full.copy_(self._rows(self.send, 0, self.total))
+            else:
+                self.recv[0].copy_(self.send)
+            return self.full
+        # flat views: gloo only takes the concatenated form (output = world x input along dimension 0)
+        dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
+        if self.full.data_ptr() != self.recv.data_ptr():
+            for r in range(self.world):
+                sz = self.sizes[r]
+                if sz:
+                    self._rows(self.full, self.offsets[r], self.offsets[r] + sz).copy_(
+                        self._rows(self.recv[r], 0, sz), non_blocking=True)
+        return self.full
+
+
+_gatherers = {}
+
+
 def all_gather_rows(local, total, group=None):
     """Gather variable-length per-rank slices of a [rows, ...] float64 array into the full
-    array on every rank (one all_gather of equal-size padded buffers).  numpy in -> numpy out; a tensor
-    comes back on the device it came from."""
+    array on every rank (one all-gather of equal-size padded slots).  numpy in -> numpy out; a tensor
+    comes back on the device it came from.  The buffers are cached per (shape, dtype, device, group)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local
-    sizes = shard_sizes(total, world)
     is_t = isinstance(local, torch.Tensor)
     t = local if is_t else torch.from_numpy(np.ascontiguousarray(local))
     home = t.device
     dev = gather_device(dist.get_backend(group), home)
-    if dev != home:
-        t = t.to(dev)
-    mx = max(sizes)
-    pad_shape = (mx,) + tuple(t.shape[1:])
-    buf = torch.zeros(pad_shape, dtype=t.dtype, device=dev)
-    buf[: t.shape[0]] = t
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)
-    full = torch.cat([o[: sizes[r]] for r, o in enumerate(outs)], dim=0)
-    if dev != home:
-        full = full.to(home)
+    key = (int(total), tuple(t.shape[1:]), t.dtype, str(dev), id(group))
+    g = _gatherers.get(key)
+    if g is None:
+        g = _gatherers[key] = RowGatherer(total, t.shape[1:], t.dtype, dev, group)
+    full = g.gather(t.to(dev) if dev != home else t)
+    full = full.to(home) if dev != home else full.clone()
     return full if is_t else full.numpy()
 
 

@@ -8,6 +8,14 @@ from oracle import ccgp_oracle as orc
 from oracle.cpu_baseline import loader as cpu
 
 
+def test_loading_the_evaluator_leaves_denormals_alone():
+    """Round-2 advisor finding: built with -ffast-math the library linked crtfastmath.o, and dlopen set FTZ/DAZ for
+    the whole process -- every numpy / scipy oracle computation after it ran with denormals flushed to zero."""
+    cpu.load()
+    assert np.float64(1e-310) * 0.5 != 0.0
+    assert np.exp(np.float64(-720.0)) != 0.0
+
+
 def test_lapack_is_bound_from_scipy_openblas():
     assert cpu.lapack_bound(), "scipy's OpenBLAS not found: the baseline would time the plain C Cholesky"
 

@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the GP log-likelihood hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg4|cfg2] [--evals-per-gpu E]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg4|cfg2|cfg3|cfg5] [--evals-per-gpu E]
 
 metric   : GP log-lik evals/sec (n x n fp64, batched over the hyperparameter grid)
 workload : cfg4 (default) = BASELINE config 4, the configuration the north_star's MFMA
            target is quoted on: synthetic 5-D design, n = 4096, K = 3 anisotropic
-           components; 64 evaluations per GPU (weak scaling: 8 GPUs = the 512-point grid).
-           cfg2 = Heat-Exchanger grid (Qian n = 64, 624 x 1000 evaluations, sharded by row).
+           components, the 512-point grid sharded over the GPUs (strong scaling: 64 per GPU at N = 8).
+           cfg2 = Heat-Exchanger grid (Qian n = 64, 624 x 1000 evaluations, sharded by grid row);
+           cfg3 = 2-D anisotropic grid on maximin-100 (60 x 1728, by grid row);
+           cfg5 = Ground-Vibrations predictive tables (17 sets x 1000 draws, sharded by draw).
 step     : one pass of the hot path over this rank's batch -- covariance build, Cholesky,
            solves, log-likelihood for every draw -- followed by the single all-gather of
            the log-likelihoods (RCCL).  Inputs (X, y, parameter matrix) are resident in HBM
            before the timed region.
-One rank per GPU; for N > 1 launch through torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE).
+One rank per GPU.  Under torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE set) this process IS a rank; a plain
+`python bench.py --gpus N` with N > 1 starts the N ranks itself as fresh child processes before touching the GPU.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -29,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r02n/pmc_traffic.json", "r02n/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
+PMC_TRAFFIC_FILES = ("r03/pmc_traffic.json", "r03/pmc_traffic64.json", "r02n/pmc_traffic.json", "r02n/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
 
 
 # ----------------------------------------------------------------------------- synthetic inputs
@@ -252,13 +255,38 @@ def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2):
             "reference_opcount": ref}
 
 
+# ----------------------------------------------------------------------------- launcher
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as FRESH child processes
+    (torch.distributed.run, one per GPU) and relay rank 0's JSON line and the children's return code.  Runs before
+    anything in this process has touched the GPU (no torch import yet), and never exec()s -- a process that has
+    initialised the GPU must not be replaced on this pool."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 # ----------------------------------------------------------------------------- main
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2"])
+    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2", "cfg3", "cfg5"],
+                    help="cfg4 = BASELINE config 4 (the headline); cfg2 / cfg3 = the hyperprior grids sharded by grid row; "
+                         "cfg5 = Ground-Vibrations predictive tables sharded by posterior draw")
     ap.add_argument("--evals-total", type=int, default=512,
                     help="cfg4: size of the hyperparameter grid, sharded over the GPUs (BASELINE config 4: 512)")
     ap.add_argument("--evals-per-gpu", type=int, default=0,
@@ -275,7 +303,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path).  gloo: rehearsal of the N > 1 code path on "
                          "a box with fewer GPUs than ranks (ranks share devices, results gathered through host memory)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -286,8 +320,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
-                         % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
     if args.backend == "gloo":
@@ -301,6 +334,43 @@ def main():
         else:
             dist.init_process_group("gloo")
     host_gather = world > 1 and args.backend == "gloo"
+    gdev = torch.device("cpu") if host_gather else dev
+    f64 = dict(dtype=torch.float64, device=dev)
+    ctx = dict(args=args, torch=torch, dist=dist, api=api, shard=shard, world=world, rank=rank, local=local, dev=dev,
+               host_gather=host_gather, gdev=gdev, f64=f64)
+    if args.workload == "cfg5":
+        run_predict_workload(ctx)
+    else:
+        run_loglik_workload(ctx)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def col_major(torch, a, **kw):
+    return torch.tensor(np.asfortranarray(a).ravel(order="F"), **kw)
+
+
+def fence(torch, dist, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(torch, dist, world, gdev, seconds):
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=gdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def run_loglik_workload(c):
+    """cfg4 (headline), cfg2, cfg3: a grid of likelihood evaluations, sharded over the ranks (the hyperprior grids by
+    grid ROW, so that a row's mean over its Halton nodes stays rank-local, HX:574), ONE all-gather per step."""
+    args, torch, dist, api, shard = c["args"], c["torch"], c["dist"], c["api"], c["shard"]
+    world, rank, local, dev, f64 = c["world"], c["rank"], c["local"], c["dev"], c["f64"]
+    host_gather, gdev = c["host_gather"], c["gdev"]
 
     mode, tau2 = api.MEAN_PROFILE_BETA, 0.0
     if args.workload == "cfg4":
@@ -309,31 +379,35 @@ def main():
         X, y, P, K = cfg4_inputs(total, n=args.n)
         sigma2 = 1.0
         lo, hi = shard.shard_bounds(total, rank, world)
+        unit_rows, units = 1, total
         wl_name = "cfg4: synthetic maximin-LHS 5-D design n=%d, K=3 anisotropic components, %d-point hyperparameter grid%s" % (
             args.n, total, " (%d per GPU)" % args.evals_per_gpu if weak else " sharded over the GPUs")
     else:
-        X, y, P, K, sigma2 = cfg2_inputs()
-        mode, tau2 = api.MEAN_ZERO_PLUS_TAU2, 50.0 ** 2
+        if args.workload == "cfg2":
+            X, y, P, K, sigma2 = cfg2_inputs()
+            tau2, unit_rows = 50.0 ** 2, 1000
+            wl_name = "cfg2: Heat-Exchanger grid, Qian n=64, 624 rows x 1000 Halton nodes, sharded by grid row"
+        else:
+            X, y, P, K, sigma2 = cfg3_inputs()
+            tau2, unit_rows = 100.0 ** 2, 1728
+            wl_name = "cfg3: 2-D anisotropic grid on maximin-100, 60 rows x 1728 Halton nodes, sharded by grid row"
+        mode = api.MEAN_ZERO_PLUS_TAU2
         total = P.shape[0]
-        G = total // 1000
-        glo, ghi = shard.shard_bounds(G, rank, world)     # shard by grid ROW (strong scaling: fixed grid)
-        lo, hi = glo * 1000, ghi * 1000
-        wl_name = "cfg2: Heat-Exchanger grid, Qian n=64, 624 rows x 1000 Halton nodes"
+        units = total // unit_rows
+        glo, ghi = shard.shard_bounds(units, rank, world)     # strong scaling: the grid is fixed
+        lo, hi = glo * unit_rows, ghi * unit_rows
     n, d = X.shape
     B = hi - lo
 
     # inputs resident in HBM (column-major, as the C ABI takes them)
-    f64 = dict(dtype=torch.float64, device=dev)
-    dX = torch.tensor(np.asfortranarray(X).ravel(order="F"), **f64)
-    dy = torch.tensor(y, **f64)
-    dP = torch.tensor(np.asfortranarray(P[lo:hi]).ravel(order="F"), **f64)
+    dX, dy = col_major(torch, X, **f64), torch.tensor(y, **f64)
+    dP = col_major(torch, P[lo:hi], **f64)
     d_ll = torch.empty(B, **f64)
     d_beta = torch.empty(B, **f64)
     d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    sizes = shard.shard_sizes(total if args.workload == "cfg4" else total, world)
-    if args.workload == "cfg2":
-        sizes = [1000 * s for s in shard.shard_sizes(total // 1000, world)]
-    gdev = dict(dtype=torch.float64, device="cpu" if host_gather else dev)
+    # the all-gather's buffers, allocated once: slots of whole grid rows (unit_rows evaluations each)
+    gat = shard.RowGatherer(units, tail=(unit_rows,), dtype=torch.float64, device=gdev) if world > 1 else None
+    h_ll = torch.empty(B, dtype=torch.float64).pin_memory() if host_gather else None
 
     # CPU legs first (rank 0, N = 1 only), so that the GPU legs that follow are one contiguous stretch of device work
     cpu_main, cpu_sec, sec_in = None, {}, None
@@ -347,6 +421,8 @@ def main():
             X3, y3, P3, K3, s23 = sec_in["cfg3"]
             cpu_sec["cfg3"] = cpu_compiled_loglik(X3, y3, P3, K3, s23, api.MEAN_ZERO_PLUS_TAU2, 1e4, 800, 2000)
             cpu_sec["cfg5"] = cpu_predict_sample(*sec_in["cfg5"])
+            if args.n == 4096:
+                cpu_sec["cfg4_predict"] = cpu_predict_n4096(X, y, K, P[:CFG4_PREDICT_DRAWS], sigma2)
 
     h = api.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -365,42 +441,45 @@ def main():
     def step():
         h.loglik_batch_dev(dX, n, d, dy, K, dP, B, sigma2, mode, tau2, d_ll, d_beta, d_st)
         if world > 1:
-            # the one collective of the path (shard.all_gather_rows: RCCL all-gather of the per-rank slices; in the
-            # gloo rehearsal the slice goes through host memory, which synchronises)
-            gathered[0] = shard.all_gather_rows(d_ll.cpu() if host_gather else d_ll, total)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            # the one collective of the path: RCCL all-gather of the per-rank slices into buffers allocated once
+            # (shard.RowGatherer); in the gloo rehearsal the slice goes through pinned host memory, which synchronises
+            if host_gather:
+                h_ll.copy_(d_ll)
+                gathered[0] = gat.gather(h_ll.view(-1, unit_rows))
+            else:
+                gathered[0] = gat.gather(d_ll.view(-1, unit_rows))
 
     for _ in range(args.warmup):
         step()
-    fence()
+    fence(torch, dist, world)
     # HIP events inside the timed region only around the launches of the roofline kernel (two event records
     # per launch are not free: 96 launch groups per step); the per-kernel breakdown comes from one extra,
-    # untimed step afterwards.
-    main_id = "update" if args.workload == "cfg4" else "fused"
-    if os.environ.get("CCGP_BENCH_NOTIMING") is None:
-        h.enable_timing(True, only=[main_id])
+    # untimed step afterwards, and a second region of the same K steps WITHOUT any event gives the cost of the
+    # in-region events (notiming_ms_per_step).
+    main_id = "update" if n > 128 else "fused"
+    h.enable_timing(True, only=[main_id])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    fence(torch, dist, world)
     elapsed = time.perf_counter() - t0
     timing = h.get_timing()
+    h.enable_timing(False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence(torch, dist, world)
+    elapsed_notiming = time.perf_counter() - t0
     h.enable_timing(True)
     step()
-    fence()
+    fence(torch, dist, world)
     breakdown = h.get_timing()
     h.enable_timing(False)
+    elapsed = max_over_ranks(torch, dist, world, gdev, elapsed)
+    elapsed_notiming = max_over_ranks(torch, dist, world, gdev, elapsed_notiming)
     if world > 1:
-        t = torch.tensor([elapsed], **gdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # every rank now holds every shard's log-likelihoods: check the gather against the local slice
-        full = gathered[0]
+        full = gathered[0].reshape(-1)
         assert full.shape[0] == total and torch.equal(full[lo:hi].to(dev), d_ll), "all-gather mismatch"
     bad = int((d_st != 0).sum().item())
     finite = bool(torch.isfinite(d_ll).all().item())
@@ -431,14 +510,16 @@ def main():
                            world, " (gloo rehearsal, ranks share devices)" if host_gather else ""),
                        "failed_evals": bad, "all_finite": finite,
                        "matches_cpu_potrf_digest": digest_ok},
+            "notiming_ms_per_step": 1e3 * elapsed_notiming / args.steps,
+            "notiming_note": "the same K steps again with no HIP event in the region (value / ms_per_step are the "
+                             "region WITH the events around the roofline kernel's launches)",
             "kernel_ms_per_step": {k: v[0] for k, v in breakdown.items() if v[1]},
             "kernel_ms_per_step_source": "one extra step with every launch group timed (outside the timed region)",
         }
-        if args.workload == "cfg4":
+        if n > 128:
             upd_ms, upd_launches = timing["update"]
             upd_ms = upd_ms or float("nan")
-            split = timing.get("update_diag", (0.0, 0))[1] > 0        # diagonal tiles launched separately
-            flops = update_kernel_flops(n, diag_tiles=not split) * B * args.steps   # this rank's launches
+            flops = update_kernel_flops(n) * B * args.steps   # this rank's launches
             ach = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
             traffic, traffic_src = pmc_traffic("chol_update", B) if n == 4096 else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -454,104 +535,248 @@ def main():
             fused_ms, fl = timing["fused"]
             flops = (n ** 3 / 3.0) * B * args.steps
             ach = flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "small_reg_kernel (register-resident fused evaluator: no MFMA and 8 P + 20 bytes of "
-                                         "HBM per evaluation; fp64 VALU-issue bound -- PMC: VALU busy 72 % of SIMD time -- so "
-                                         "n^3/3 flop per evaluation is priced against the fp64 peak, which is the same "
-                                         "78.6 TFLOP/s for vector and matrix instructions on this chip; see DESIGN.md)",
-                               "launches": fl, "avg_launch_ms": fused_ms / max(fl, 1)}
+            out["roofline"] = small_roofline(ach, fl, fused_ms)
         if cpu_main is not None:
             out["cpu_baseline"] = cpu_main
         if sec_in is not None:
-            # secondary line item: the Heat-Exchanger grid (BASELINE config 2) on the same GPU
-            X2, y2, P2, K2, s22 = sec_in["cfg2"]
-            dX2 = torch.tensor(np.asfortranarray(X2).ravel(order="F"), **f64)
-            dy2 = torch.tensor(y2, **f64)
-            dP2 = torch.tensor(np.asfortranarray(P2).ravel(order="F"), **f64)
-            B2 = P2.shape[0]
-            o1, o2 = torch.empty(B2, **f64), torch.empty(B2, **f64)
-            o3 = torch.zeros(B2, dtype=torch.int32, device=dev)
-            for it in range(3):
-                if it == 1:
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                h.loglik_batch_dev(dX2, 64, 4, dy2, K2, dP2, B2, s22, api.MEAN_ZERO_PLUS_TAU2, 2500.0, o1, o2, o3)
-            torch.cuda.synchronize()
-            el2 = (time.perf_counter() - t1) / 2
-            out["secondary"] = [{"workload": "cfg2: Heat-Exchanger grid, Qian n=64, 624 x 1000 evals",
-                                 "value": B2 / el2, "unit": "evals/s", "ms_per_pass": 1e3 * el2,
-                                 "failed_evals": int((o3 != 0).sum().item())}]
-            # config 3: 2-D anisotropic grid on maximin-100 (60 x 1728 evaluations at n = 100)
-            X3, y3, P3, K3, s23 = sec_in["cfg3"]
-            dX3 = torch.tensor(np.asfortranarray(X3).ravel(order="F"), **f64)
-            dy3 = torch.tensor(y3, **f64)
-            dP3 = torch.tensor(np.asfortranarray(P3).ravel(order="F"), **f64)
-            B3 = P3.shape[0]
-            q1, q2 = torch.empty(B3, **f64), torch.empty(B3, **f64)
-            q3 = torch.zeros(B3, dtype=torch.int32, device=dev)
-            for it in range(3):
-                if it == 1:
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                h.loglik_batch_dev(dX3, 100, 2, dy3, K3, dP3, B3, s23, api.MEAN_ZERO_PLUS_TAU2, 1e4, q1, q2, q3)
-            torch.cuda.synchronize()
-            el3 = (time.perf_counter() - t1) / 2
-            out["secondary"].append({"workload": "cfg3: 2-D anisotropic grid, maximin-100, 60 x 1728 evals",
-                                     "value": B3 / el3, "unit": "evals/s", "ms_per_pass": 1e3 * el3,
-                                     "failed_evals": int((q3 != 0).sum().item())})
-            # config 5: Ground-Vibrations predictive mean/variance tables, all 17 train/test pairs
-            sets, P5 = sec_in["cfg5"]
-            S5 = P5.shape[0]
-            dP5 = torch.tensor(np.asfortranarray(P5).ravel(order="F"), **f64)
-            dsets, pairs = [], 0
-            for (Xs, ys, Xt) in sets:
-                m5 = Xt.shape[0]
-                pairs += S5 * m5
-                dsets.append((torch.tensor(np.asfortranarray(Xs).ravel(order="F"), **f64), torch.tensor(ys, **f64),
-                              torch.tensor(np.asfortranarray(Xt).ravel(order="F"), **f64), Xs.shape[0], m5,
-                              torch.empty(S5 * m5, **f64), torch.empty(S5 * m5, **f64), torch.empty(S5, **f64),
-                              torch.zeros(S5, dtype=torch.int32, device=dev)))
-            for it in range(3):
-                if it == 1:
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                for (a1, a2, a3, n5, m5, o_m, o_v, o_b, o_s) in dsets:
-                    h.predict_batch_dev(a1, n5, 9, a2, 2, dP5, S5, a3, m5, float(1.0), o_m, o_v, o_b, o_s)
-            torch.cuda.synchronize()
-            el5 = (time.perf_counter() - t1) / 2
-            out["secondary"].append({"workload": "cfg5: Ground-Vibrations predictive tables, 17 sets x 1000 draws x (150|110) test points",
-                                     "value": pairs / el5, "unit": "(draw, test point) predictions/s",
-                                     "ms_per_pass": 1e3 * el5,
-                                     "failed_draws": int(sum(int((t[8] != 0).sum().item()) for t in dsets))})
-            for entry, key in zip(out["secondary"], ("cfg2", "cfg3", "cfg5")):
-                entry["cpu"] = cpu_sec.get(key)
-            # prediction at a second test set from factors kept in HBM, against re-factorising
-            if args.workload == "cfg4" and n == 4096:
-                Sf, mf_ = 16, 128
-                Xt = np.random.default_rng(5).random((mf_, d))
-                t1 = time.perf_counter()
-                fs = h.factor_batch(X, y, K, P[:Sf], sigma2)
-                t_fac = time.perf_counter() - t1
-                fs.predict(Xt)
-                t1 = time.perf_counter()
-                m_a, v_a = fs.predict(Xt)
-                t_keep = time.perf_counter() - t1
-                h.predict_batch(X, y, K, P[:Sf], Xt, sigma2)
-                t1 = time.perf_counter()
-                m_b, v_b, _, _ = h.predict_batch(X, y, K, P[:Sf], Xt, sigma2)
-                t_full = time.perf_counter() - t1
-                out["secondary"].append({
-                    "workload": "cfg4 prediction: n=4096, %d draws, %d test sites" % (Sf, mf_),
-                    "value": Sf * mf_ / t_keep, "unit": "(draw, test point) predictions/s from a kept factor set",
-                    "ms_from_factorset": 1e3 * t_keep, "ms_refactorising": 1e3 * t_full, "ms_factor_batch": 1e3 * t_fac,
-                    "factorset_bytes": fs.nbytes, "identical": bool(np.array_equal(m_a, m_b) and np.array_equal(v_a, v_b)),
-                    "cpu": None})
-                fs.free()
-        print(json.dumps(out))
+            out["secondary"] = secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2)
+        print(json.dumps(out), flush=True)
     h.close()
-    if world > 1:
-        dist.destroy_process_group()
+
+
+def small_roofline(ach, launches, fused_ms):
+    return {"bound": "valu-issue", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "small_reg_kernel (register-resident fused evaluator: 8 P + 20 bytes of HBM per evaluation, so "
+                      "neither HBM nor -- for the VALU form -- MFMA bounds it; it is fp64 VALU-issue bound, and n^3/3 flop "
+                      "per evaluation is priced against the fp64 peak, which is the same 78.6 TFLOP/s for vector and "
+                      "matrix instructions on this chip; see DESIGN.md K2)",
+            "launches": launches, "avg_launch_ms": fused_ms / max(launches, 1)}
+
+
+def timed_passes(torch, fn, passes=2):
+    """One untimed pass, then `passes` timed ones (wall clock around a device synchronise): seconds per pass."""
+    fn()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(passes):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t1) / passes
+
+
+CFG4_PREDICT_DRAWS, CFG4_PREDICT_SITES = 16, 128
+
+
+def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
+    """BASELINE configs 2, 3, 5 and the factor-set prediction on the same GPU (N = 1 only), each as the kernel-level
+    figure (inputs resident in HBM) AND -- round 3 -- end to end through the host-pointer entry point the reference's
+    caller would bind (`choose.hyperpars` -> ccgp_grid_marginal, `prediction` -> ccgp_predict_batch)."""
+    torch, api, dev, f64 = c["torch"], c["api"], c["dev"], c["f64"]
+    args = c["args"]
+    items = []
+    from ccgp_amd.tables import read_table
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    # config 2: the Heat-Exchanger grid
+    X2, y2, P2, K2, s22 = sec_in["cfg2"]
+    dX2, dy2, dP2 = col_major(torch, X2, **f64), torch.tensor(y2, **f64), col_major(torch, P2, **f64)
+    B2 = P2.shape[0]
+    o1, o2 = torch.empty(B2, **f64), torch.empty(B2, **f64)
+    o3 = torch.zeros(B2, dtype=torch.int32, device=dev)
+    el2 = timed_passes(torch, lambda: h.loglik_batch_dev(dX2, 64, 4, dy2, K2, dP2, B2, s22, api.MEAN_ZERO_PLUS_TAU2,
+                                                         2500.0, o1, o2, o3))
+    _, H2 = read_table(os.path.join(data, "hx_hyperpars_matrix.txt"))
+    res2 = [None]
+
+    def grid2():
+        res2[0] = h.grid_marginal(X2, y2, s22, H2, 1000, 50.0, True)
+    e2e2 = timed_passes(torch, grid2, passes=3)
+    items.append({"workload": "cfg2: Heat-Exchanger grid, Qian n=64, 624 x 1000 evals",
+                  "value": B2 / el2, "unit": "evals/s", "ms_per_pass": 1e3 * el2,
+                  "failed_evals": int((o3 != 0).sum().item()),
+                  "end_to_end": {"call": "Handle.grid_marginal = ccgp_grid_marginal (host pointers; what choose.hyperpars "
+                                         "HX:584-595 binds): G x 4 hyperparameters in, G values + argmax out, the G x N "
+                                         "draws built on the device",
+                                 "ms_per_call": 1e3 * e2e2, "evals_per_s": B2 / e2e2,
+                                 "over_kernel": e2e2 / el2, "argmax_row_1based": int(res2[0][1]) + 1}})
+    # config 3: 2-D anisotropic grid on maximin-100 (60 x 1728 evaluations at n = 100)
+    X3, y3, P3, K3, s23 = sec_in["cfg3"]
+    dX3, dy3, dP3 = col_major(torch, X3, **f64), torch.tensor(y3, **f64), col_major(torch, P3, **f64)
+    B3 = P3.shape[0]
+    q1, q2 = torch.empty(B3, **f64), torch.empty(B3, **f64)
+    q3 = torch.zeros(B3, dtype=torch.int32, device=dev)
+    el3 = timed_passes(torch, lambda: h.loglik_batch_dev(dX3, 100, 2, dy3, K3, dP3, B3, s23, api.MEAN_ZERO_PLUS_TAU2,
+                                                         1e4, q1, q2, q3))
+    _, H3 = read_table(os.path.join(data, "adv_hyperpars_matrix.txt"))
+    H3 = H3 * np.array([1.0, 16.0, 1.0, 16.0])
+    e2e3 = timed_passes(torch, lambda: h.grid_marginal(X3, y3, s23, H3, 1728, 100.0, False, aniso_lambda=4.0), passes=3)
+    items.append({"workload": "cfg3: 2-D anisotropic grid, maximin-100, 60 x 1728 evals",
+                  "value": B3 / el3, "unit": "evals/s", "ms_per_pass": 1e3 * el3,
+                  "failed_evals": int((q3 != 0).sum().item()),
+                  "end_to_end": {"call": "Handle.grid_marginal (host pointers)", "ms_per_call": 1e3 * e2e3,
+                                 "evals_per_s": B3 / e2e3, "over_kernel": e2e3 / el3}})
+    # config 5: Ground-Vibrations predictive mean/variance tables, all 17 train/test pairs
+    sets, P5 = sec_in["cfg5"]
+    S5 = P5.shape[0]
+    dP5 = col_major(torch, P5, **f64)
+    dsets, pairs = [], 0
+    for (Xs, ys, Xt) in sets:
+        m5 = Xt.shape[0]
+        pairs += S5 * m5
+        dsets.append((col_major(torch, Xs, **f64), torch.tensor(ys, **f64), col_major(torch, Xt, **f64), Xs.shape[0], m5,
+                      torch.empty(S5 * m5, **f64), torch.empty(S5 * m5, **f64), torch.empty(S5, **f64),
+                      torch.zeros(S5, dtype=torch.int32, device=dev)))
+
+    def pass5():
+        for (a1, a2, a3, n5, m5, o_m, o_v, o_b, o_s) in dsets:
+            h.predict_batch_dev(a1, n5, 9, a2, 2, dP5, S5, a3, m5, float(1.0), o_m, o_v, o_b, o_s)
+
+    def pass5_host():
+        for (Xs, ys, Xt) in sets:
+            h.predict_batch(Xs, ys, 2, P5, Xt, 1.0)
+    el5 = timed_passes(torch, pass5)
+    e2e5 = timed_passes(torch, pass5_host)
+    items.append({"workload": "cfg5: Ground-Vibrations predictive tables, 17 sets x 1000 draws x (150|110) test points",
+                  "value": pairs / el5, "unit": "(draw, test point) predictions/s",
+                  "ms_per_pass": 1e3 * el5,
+                  "failed_draws": int(sum(int((t[8] != 0).sum().item()) for t in dsets)),
+                  "end_to_end": {"call": "Handle.predict_batch = ccgp_predict_batch (host pointers; the table prediction() "
+                                         "HX:686-693 averages), one call per train/test pair",
+                                 "ms_per_pass": 1e3 * e2e5, "predictions_per_s": pairs / e2e5, "over_kernel": e2e5 / el5}})
+    for entry, key in zip(items, ("cfg2", "cfg3", "cfg5")):
+        entry["cpu"] = cpu_sec.get(key)
+    # SURVEY 8(f)-2: prediction at a second test set from factors kept in HBM, against re-factorising
+    if args.workload == "cfg4" and X.shape[0] == 4096:
+        Sf, mf_ = CFG4_PREDICT_DRAWS, CFG4_PREDICT_SITES
+        Xt = cfg4_predict_sites(X.shape[1])
+        t1 = time.perf_counter()
+        fs = h.factor_batch(X, y, K, P[:Sf], sigma2)
+        t_fac = time.perf_counter() - t1
+        fs.predict(Xt)
+        t1 = time.perf_counter()
+        m_a, v_a = fs.predict(Xt)
+        t_keep = time.perf_counter() - t1
+        h.predict_batch(X, y, K, P[:Sf], Xt, sigma2)
+        t1 = time.perf_counter()
+        m_b, v_b, _, _ = h.predict_batch(X, y, K, P[:Sf], Xt, sigma2)
+        t_full = time.perf_counter() - t1
+        items.append({
+            "workload": "cfg4 prediction: n=4096, %d draws, %d test sites" % (Sf, mf_),
+            "value": Sf * mf_ / t_keep, "unit": "(draw, test point) predictions/s from a kept factor set",
+            "ms_from_factorset": 1e3 * t_keep, "ms_refactorising": 1e3 * t_full, "ms_factor_batch": 1e3 * t_fac,
+            "factorset_bytes": fs.nbytes, "identical": bool(np.array_equal(m_a, m_b) and np.array_equal(v_a, v_b)),
+            "cpu": cpu_sec.get("cfg4_predict")})
+        fs.free()
+    return items
+
+
+def cfg4_predict_sites(d):
+    return np.random.default_rng(5).random((CFG4_PREDICT_SITES, d))
+
+
+def cpu_predict_n4096(X, y, K, P, sigma2):
+    """The compiled CPU evaluator on the factor-set workload (n = 4096, 16 draws x 128 sites: one draw per core)."""
+    from oracle.cpu_baseline import loader as cpu
+    cores = cpu.max_threads()
+    Xt = cfg4_predict_sites(X.shape[1])
+    t0 = time.perf_counter()
+    cpu.predict_batch(X, y, K, P, Xt, sigma2, threads=cores)
+    el = time.perf_counter() - t0
+    return {"all_cores": P.shape[0] * Xt.shape[0] / el, "cores": cores, "unit": "(draw, test point) predictions/s",
+            "ms": 1e3 * el, "sample": "%d draws x %d sites, re-factorising (covariance + dpotrf + %d dtrsv per draw), one draw "
+                                      "per core on %d cores in %.2f s" % (P.shape[0], Xt.shape[0], Xt.shape[0] + 2, cores, el)}
+
+
+def run_predict_workload(c):
+    """cfg5 (BASELINE config 5): the (posterior draw x test point) predictive mean / variance tables of all 17
+    Ground-Vibrations train/test pairs, sharded over the ranks BY DRAW; ONE all-gather per step collects the
+    S x (sum of m) x 2 table (every rank then holds what prediction() averages, HX:688-693)."""
+    args, torch, dist, api, shard = c["args"], c["torch"], c["dist"], c["api"], c["shard"]
+    world, rank, local, dev, f64 = c["world"], c["rank"], c["local"], c["dev"], c["f64"]
+    host_gather, gdev = c["host_gather"], c["gdev"]
+    sets, P5 = cfg5_inputs()
+    S = P5.shape[0]
+    lo, hi = shard.shard_bounds(S, rank, world)
+    Sl = hi - lo
+    M = sum(t[2].shape[0] for t in sets)
+    dP = col_major(torch, P5[lo:hi], **f64)
+    # a device table S_local x m column-major is a row-major [m, S_local] block: all 17 sets' mean and variance tables
+    # stacked give [2 M, S_local]; the draws are the gathered (last) dimension
+    gat = shard.RowGatherer(S, lead=(2 * M,), dtype=torch.float64, device=gdev)
+    direct = (not host_gather) and Sl == gat.slot      # compute straight into the send buffer
+    table = gat.send if direct else torch.empty((2 * M, Sl), **f64)
+    h_table = torch.empty((2 * M, Sl), dtype=torch.float64).pin_memory() if host_gather else None
+    d_beta = torch.empty(Sl, **f64)
+    d_st = torch.zeros(Sl, dtype=torch.int32, device=dev)
+    dsets, off = [], 0
+    for (Xs, ys, Xt) in sets:
+        m = Xt.shape[0]
+        dsets.append((col_major(torch, Xs, **f64), torch.tensor(ys, **f64), col_major(torch, Xt, **f64), Xs.shape[0], m,
+                      table[off:off + m], table[M + off:M + off + m]))
+        off += m
+    cpu5 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu5 = cpu_predict_sample(sets, P5)
+    h = api.Handle(local)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    full = [None]
+    bad = [0]
+
+    def step():
+        for (a1, a2, a3, n5, m5, o_m, o_v) in dsets:
+            h.predict_batch_dev(a1, n5, 9, a2, 2, dP, Sl, a3, m5, 1.0, o_m, o_v, d_beta, d_st)
+        if host_gather:
+            h_table.copy_(table)
+            full[0] = gat.gather(h_table)
+        else:
+            full[0] = gat.gather(None if direct else table)
+
+    for _ in range(args.warmup):
+        step()
+    fence(torch, dist, world)
+    h.enable_timing(True, only=["fused"])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence(torch, dist, world)
+    elapsed = time.perf_counter() - t0
+    timing = h.get_timing()
+    h.enable_timing(False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence(torch, dist, world)
+    elapsed_notiming = time.perf_counter() - t0
+    elapsed = max_over_ranks(torch, dist, world, gdev, elapsed)
+    elapsed_notiming = max_over_ranks(torch, dist, world, gdev, elapsed_notiming)
+    bad[0] = int((d_st != 0).sum().item())
+    got = full[0]
+    assert tuple(got.shape) == (2 * M, S), got.shape
+    assert torch.equal(got[:, lo:hi].to(dev), table), "all-gather mismatch"
+    finite = bool(torch.isfinite(got).all().item())
+    if rank == 0:
+        pairs = S * M
+        fused_ms, fl = timing["fused"]
+        # useful flop per draw and set: n^3/3 (factor) + m n^2 (forward substitution of the m cross-correlation rows)
+        flops = sum((t[0].shape[0] ** 3 / 3.0 + t[2].shape[0] * t[0].shape[0] ** 2) for t in sets) * Sl * args.steps
+        ach = flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0
+        out = {"metric": "GP predictive mean/variance, (draw x test point) predictions/sec (BASELINE config 5)",
+               "value": pairs * args.steps / elapsed, "unit": "(draw, test point) predictions/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "cfg5: Ground-Vibrations predictive tables, 17 train/test pairs (n = 50 | 90, d = 9), "
+                                      "%d synthetic posterior draws x %d test points in total, sharded by draw" % (S, M),
+                          "draws_total": S, "draws_per_gpu": Sl, "test_points_total": M,
+                          "parallelism": "draws sharded over %d GPU(s), one all-gather of the S x M x 2 table%s" % (
+                              world, " (gloo rehearsal, ranks share devices)" if host_gather else ""),
+                          "gathered_bytes": int(2 * M * S * 8), "failed_draws": bad[0], "all_finite": finite},
+               "notiming_ms_per_step": 1e3 * elapsed_notiming / args.steps,
+               "roofline": small_roofline(ach, fl, fused_ms)}
+        if cpu5 is not None:
+            out["cpu_baseline"] = {"value": cpu5["all_cores"], "unit": cpu5["unit"], "cores": cpu5["cores"], "kind": "port",
+                                   "sample": cpu5["sample"], "one_core": cpu5["one_core"], "model": cpu_model()}
+        print(json.dumps(out), flush=True)
+    h.close()
 
 
 if __name__ == "__main__":

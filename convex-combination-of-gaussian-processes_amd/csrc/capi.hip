@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "ccgp_internal.h"
+#include "special_math.h"
 
 using namespace ccgp;
 
@@ -262,6 +263,51 @@ __global__ void row_logmeanexp_kernel(const double* logs, int N, int take_log, d
     if (anynan) v = __longlong_as_double(0x7ff8000000000000LL);
     out[g] = v;
   }
+}
+
+// ---- hyperprior grid: the G x N table of draws, built on the device (likeli.hyperpars HX:554-559) ----------
+// qtab[s * N + j] = qgamma(1 - u_j, shape_s, rate 1),  u_j = runif.halton(N, 1)[j]
+__global__ void grid_qtab_kernel(const double* shapes, int ns, int N, double* qtab) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ns * N) return;
+  const int s = idx / N, j = idx % N;
+  qtab[idx] = qgamma_unit(1.0 - halton2((unsigned)j + 1u), shapes[s]);
+}
+
+// draw b = g N + j: p = u_j, theta1 = qigamma(u_j, a1, b1) = b1 / qtab[a1][j], theta2 likewise (HX:554-556);
+// isotropic: theta_c repeated over the d dimensions; anisotropic (ANI:399-406 with the grid's quantiles per
+// dimension, BASELINE config 3): component 1 = (theta1, theta2), component 2 = (1 + lambda) (theta1, theta2)
+__global__ void grid_expand_kernel(const double* hyper, const int* shape_idx, const double* qtab, int G, int N,
+                                   int d, int aniso, double lambda, double* params) {
+  const size_t B = (size_t)G * N;
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int g = (int)(b / N), j = (int)(b % N);
+  const double p = halton2((unsigned)j + 1u);
+  const double th1 = hyper[g + (size_t)G] / qtab[(size_t)shape_idx[g] * N + j];
+  const double th2 = hyper[g + (size_t)3 * G] / qtab[(size_t)shape_idx[G + g] * N + j];
+  params[b] = p;
+  params[b + B] = 1.0 - p;
+  if (aniso) {
+    params[b + 2 * B] = th1;
+    params[b + 3 * B] = th2;
+    params[b + 4 * B] = (1.0 + lambda) * th1;
+    params[b + 5 * B] = (1.0 + lambda) * th2;
+  } else {
+    for (int k = 0; k < d; ++k) {
+      params[b + (size_t)(2 + k) * B] = th1;
+      params[b + (size_t)(2 + d + k) * B] = th2;
+    }
+  }
+}
+
+// number of evaluations whose factorisation met a non-positive pivot (the C ABI's positive return value)
+__global__ void count_bad_kernel(const int* status, int B, int* out) {
+  int c = 0;
+  const int end = min(B, (int)(blockIdx.x + 1) * 1024);
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < end; i += 256) c += status[i] != 0;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
 }  // namespace
@@ -839,7 +885,7 @@ int ccgp_halton_base2(int N, double* out) {
 
 int ccgp_qigamma(const double* p, int N, double alpha, double beta, double* out) {
   if (N < 0 || !p || !out || !(alpha > 0.0) || !(beta > 0.0)) return CCGP_EINVAL;
-  for (int i = 0; i < N; ++i) out[i] = qigamma(p[i], alpha, beta);
+  for (int i = 0; i < N; ++i) out[i] = qigamma_host(p[i], alpha, beta);
   return CCGP_OK;
 }
 
@@ -855,68 +901,73 @@ int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const doub
   const int K = 2, P = K + K * d;
   const size_t B = (size_t)G * N;
   if (B > (size_t)1 << 30) return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: G*N too large");
-  std::vector<double> u(N);
-  halton_base2(N, u.data());
-  // unit-rate gamma quantiles per distinct shape (the same Halton node drives p, theta1, theta2)
-  std::map<double, std::vector<double>> qcache;
-  auto quant = [&](double alpha) -> const std::vector<double>& {
-    auto it = qcache.find(alpha);
-    if (it != qcache.end()) return it->second;
-    std::vector<double> q(N);
-    for (int j = 0; j < N; ++j) q[j] = qgamma_unit(1.0 - u[j], alpha);
-    return qcache.emplace(alpha, std::move(q)).first->second;
-  };
-  std::vector<double> params(B * P);
-  for (int g = 0; g < G; ++g) {
-    const double a1 = hyper[g], b1 = hyper[g + (size_t)G], a2 = hyper[g + (size_t)2 * G],
-                 b2 = hyper[g + (size_t)3 * G];
-    if (!(a1 > 0.0) || !(b1 > 0.0) || !(a2 > 0.0) || !(b2 > 0.0))
-      return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: hyperparameters must be positive");
-    const std::vector<double>& q1 = quant(a1);
-    const std::vector<double>& q2 = quant(a2);
-    for (int j = 0; j < N; ++j) {
-      const size_t b = (size_t)g * N + j;
-      const double p = u[j], th1 = b1 / q1[j], th2 = b2 / q2[j];
-      params[b] = p;
-      params[b + B] = 1.0 - p;
-      if (aniso) {
-        params[b + 2 * B] = th1;
-        params[b + 3 * B] = th2;
-        params[b + 4 * B] = (1.0 + aniso_lambda) * th1;
-        params[b + 5 * B] = (1.0 + aniso_lambda) * th2;
-      } else {
-        for (int k = 0; k < d; ++k) {
-          params[b + (size_t)(2 + k) * B] = th1;
-          params[b + (size_t)(2 + d + k) * B] = th2;
+  // What crosses PCIe: X, y, the G x 4 hyperparameter matrix and the list of DISTINCT inverse-gamma shapes
+  // (a few KB) in; G doubles and one failure count out.  The G x N table of draws is built in HBM:
+  // unit-rate gamma quantiles per distinct shape (grid_qtab_kernel; the same Halton node drives p, theta1 and
+  // theta2, HX:554-556), then the parameter rows (grid_expand_kernel).
+  std::vector<double> shapes;
+  std::vector<int> shape_idx(2 * (size_t)G);
+  {
+    std::map<double, int> seen;
+    for (int g = 0; g < G; ++g) {
+      const double a1 = hyper[g], b1 = hyper[g + (size_t)G], a2 = hyper[g + (size_t)2 * G],
+                   b2 = hyper[g + (size_t)3 * G];
+      if (!(a1 > 0.0) || !(b1 > 0.0) || !(a2 > 0.0) || !(b2 > 0.0))
+        return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: hyperparameters must be positive");
+      for (int w = 0; w < 2; ++w) {
+        const double al = w ? a2 : a1;
+        auto it = seen.find(al);
+        if (it == seen.end()) {
+          it = seen.emplace(al, (int)shapes.size()).first;
+          shapes.push_back(al);
         }
+        shape_idx[(size_t)w * G + g] = it->second;
       }
     }
   }
+  const size_t ns = shapes.size();
   size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
+                Carver::al(sizeof(double) * 4 * G) + Carver::al(sizeof(double) * ns) +
+                Carver::al(sizeof(int) * 2 * G) + Carver::al(sizeof(double) * ns * N) +
                 Carver::al(sizeof(double) * B * P) + 2 * Carver::al(sizeof(double) * B) +
-                Carver::al(sizeof(int) * B) + Carver::al(sizeof(double) * G);
+                Carver::al(sizeof(int) * B) + Carver::al(sizeof(double) * G) + Carver::al(sizeof(int));
   int rc = ensure_stage(h, need);
   if (rc) return rc;
   Carver c(h->stage);
   double* dX = c.take<double>((size_t)n * d);
   double* dy = c.take<double>(n);
+  double* dhy = c.take<double>((size_t)4 * G);
+  double* dsh = c.take<double>(ns);
+  int* dsi = c.take<int>((size_t)2 * G);
+  double* dq = c.take<double>(ns * N);
   double* dp = c.take<double>(B * P);
   double* dll = c.take<double>(B);
   double* dbeta = c.take<double>(B);
   int* dst = c.take<int>(B);
   double* dout = c.take<double>(G);
+  int* dbad = c.take<int>(1);
   CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
   CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dp, params.data(), sizeof(double) * B * P, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dhy, hyper, sizeof(double) * 4 * (size_t)G, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dsh, shapes.data(), sizeof(double) * ns, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemcpyAsync(dsi, shape_idx.data(), sizeof(int) * 2 * (size_t)G, hipMemcpyHostToDevice, h->stream));
+  CCGP_HIP(hipMemsetAsync(dbad, 0, sizeof(int), h->stream));
+  {
+    ScopedTimer t(h, CCGP_T_COV);
+    hipLaunchKernelGGL(grid_qtab_kernel, dim3((unsigned)((ns * N + 255) / 256)), dim3(256), 0, h->stream, dsh, (int)ns, N, dq);
+    hipLaunchKernelGGL(grid_expand_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, dhy, dsi, dq, G, N,
+                       d, aniso ? 1 : 0, aniso_lambda, dp);
+  }
   rc = loglik_dev(h, dX, n, d, dy, K, dp, (int)B, sigma2, CCGP_MEAN_ZERO_PLUS_TAU2, tau * tau, dll,
                   dbeta, dst);
   if (rc) return rc;
   hipLaunchKernelGGL(row_logmeanexp_kernel, dim3(G), dim3(256), 0, h->stream, dll, N, take_log, dout);
+  hipLaunchKernelGGL(count_bad_kernel, dim3((unsigned)((B + 1023) / 1024)), dim3(256), 0, h->stream, dst, (int)B, dbad);
   CCGP_LAUNCH_CHECK();
+  int bad = 0;
   CCGP_HIP(hipMemcpyAsync(out, dout, sizeof(double) * G, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (out_logs) CCGP_HIP(hipMemcpyAsync(out_logs, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
-  std::vector<int> st(B);
-  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
   CCGP_HIP(hipStreamSynchronize(h->stream));
   if (out_argmax) {
     // which.max: first maximum, NaN skipped
@@ -925,7 +976,7 @@ int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const doub
       if (out[g] == out[g] && (best < 0 || out[g] > out[best])) best = g;
     *out_argmax = best;
   }
-  return count_bad(st.data(), (int)B);
+  return bad;
 }
 
 // ---- a10/a11: prediction -------------------------------------------------------------------------

@@ -158,8 +158,7 @@ void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int
 
 // ---- special.cpp ---------------------------------------------------------------------
 void halton_base2(int N, double* out);
-double qgamma_unit(double p, double shape);  // quantile of Gamma(shape, rate 1)
-double qigamma(double p, double alpha, double beta);
+double qigamma_host(double p, double alpha, double beta);   // the __host__ __device__ originals: special_math.h
 
 // ---- helpers -------------------------------------------------------------------------
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

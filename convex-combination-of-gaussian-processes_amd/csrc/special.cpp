@@ -1,116 +1,14 @@
-// Host-side quadrature nodes of likeli.hyperpars (HX:554-556, ADV:557-559).
-//
-// The reference takes them from two CRAN packages whose sources are not in its tree:
-//   fOptions::runif.halton(N, 1)  -> base-2 radical inverse of 1..N
-//   pscl::qigamma(p, alpha, beta) -> 1 / qgamma(1 - p, shape = alpha, rate = beta)
-// Both are restated here from their mathematical definitions; tests compare against
-// scipy.stats (tests/test_special.py).
-#include <cmath>
-#include <limits>
+// Host entry points of the quadrature helpers (special_math.h) behind ccgp_halton_base2 / ccgp_qigamma.
+#include "special_math.h"
 
 #include "ccgp_internal.h"
 
 namespace ccgp {
 
 void halton_base2(int N, double* out) {
-  for (int i = 1; i <= N; ++i) {
-    double f = 0.5, r = 0.0;
-    for (unsigned k = static_cast<unsigned>(i); k; k >>= 1) {
-      if (k & 1u) r += f;
-      f *= 0.5;
-    }
-    out[i - 1] = r;
-  }
+  for (int i = 1; i <= N; ++i) out[i - 1] = halton2(static_cast<unsigned>(i));
 }
 
-namespace {
-
-// regularised incomplete gamma: lower P by series (x < a+1), upper Q by Lentz continued
-// fraction (x >= a+1).  Returns the requested tail computed WITHOUT subtracting from 1
-// whenever the direct form applies, so small tails keep full relative accuracy.
-double log_prefactor(double a, double x) { return a * std::log(x) - x - std::lgamma(a); }
-
-double p_series(double a, double x) {
-  double sum = 1.0 / a, term = sum;
-  for (int n = 1; n < 2000; ++n) {
-    term *= x / (a + n);
-    sum += term;
-    if (std::fabs(term) < std::fabs(sum) * 1e-17) break;
-  }
-  return sum * std::exp(log_prefactor(a, x));
-}
-
-double q_contfrac(double a, double x) {
-  const double tiny = 1e-300;
-  double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
-  for (int i = 1; i < 2000; ++i) {
-    double an = -i * (i - a);
-    b += 2.0;
-    d = an * d + b;
-    if (std::fabs(d) < tiny) d = tiny;
-    c = b + an / c;
-    if (std::fabs(c) < tiny) c = tiny;
-    d = 1.0 / d;
-    double del = d * c;
-    h *= del;
-    if (std::fabs(del - 1.0) < 1e-16) break;
-  }
-  return std::exp(log_prefactor(a, x)) * h;
-}
-
-double gamma_p(double a, double x) {
-  if (x <= 0.0) return 0.0;
-  return x < a + 1.0 ? p_series(a, x) : 1.0 - q_contfrac(a, x);
-}
-double gamma_q(double a, double x) {
-  if (x <= 0.0) return 1.0;
-  return x < a + 1.0 ? 1.0 - p_series(a, x) : q_contfrac(a, x);
-}
-
-}  // namespace
-
-// x such that P(shape, x) = p, i.e. qgamma(p, shape, rate = 1).
-double qgamma_unit(double p, double a) {
-  if (!(p > 0.0)) return 0.0;
-  if (!(p < 1.0)) return std::numeric_limits<double>::infinity();
-  const double q = 1.0 - p;
-  // starting value (Wilson-Hilferty for a > 1, small-shape expansion otherwise)
-  double x;
-  if (a > 1.0) {
-    const double pp = p < 0.5 ? p : q;
-    const double t = std::sqrt(-2.0 * std::log(pp));
-    double z = (2.30753 + t * 0.27061) / (1.0 + t * (0.99229 + t * 0.04481)) - t;
-    if (p < 0.5) z = -z;
-    const double w = 1.0 - 1.0 / (9.0 * a) - z / (3.0 * std::sqrt(a));
-    x = a * w * w * w;
-    if (x < 1e-3) x = 1e-3;
-  } else {
-    const double t = 1.0 - a * (0.253 + a * 0.12);
-    x = p < t ? std::pow(p / t, 1.0 / a) : 1.0 - std::log(1.0 - (p - t) / (1.0 - t));
-  }
-  const double lg = std::lgamma(a);
-  for (int it = 0; it < 100; ++it) {
-    if (x <= 0.0) x = 1e-300;
-    // residual in the smaller tail
-    const double err = p <= 0.5 ? gamma_p(a, x) - p : q - gamma_q(a, x);
-    const double dens = std::exp(-x + (a - 1.0) * std::log(x) - lg);
-    if (dens == 0.0) break;
-    const double u = err / dens;
-    double corr = u * ((a - 1.0) / x - 1.0);
-    if (corr > 1.0) corr = 1.0;
-    double dx = u / (1.0 - 0.5 * corr);
-    double xn = x - dx;
-    if (xn <= 0.0) xn = 0.5 * x;
-    const double step = std::fabs(xn - x);
-    x = xn;
-    if (step <= 4e-16 * x) break;
-  }
-  return x;
-}
-
-double qigamma(double p, double alpha, double beta) {
-  // 1 / qgamma(1 - p, alpha, rate beta) = beta / qgamma_unit(1 - p, alpha)
-  return beta / qgamma_unit(1.0 - p, alpha);
-}
+double qigamma_host(double p, double alpha, double beta) { return qigamma(p, alpha, beta); }
 
 }  // namespace ccgp

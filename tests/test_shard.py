@@ -114,3 +114,58 @@ def test_gather_buffers_are_staged_on_the_gpu_for_rccl():
     assert sh.gather_device("gloo", cuda1) == cuda1
     if torch.cuda.is_available():
         assert sh.gather_device("nccl", cpu).type == "cuda"
+
+
+def _gatherer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import ccgp_amd  # noqa: F401
+    from ccgp_amd import shard as sh
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    # (a) the likelihood vector of a hyperprior grid: 5 grid rows of 4 nodes over 3 ranks (ragged: 2, 2, 1)
+    g = sh.RowGatherer(5, tail=(4,))
+    lo, hi = sh.shard_bounds(5, rank, world)
+    whole = torch.arange(20, dtype=torch.float64).view(5, 4)
+    ptr = (g.send.data_ptr(), g.recv.data_ptr(), g.full.data_ptr())
+    for it in range(3):                                   # repeated calls reuse the same three buffers
+        out = g.gather(whole[lo:hi] + it)
+        assert torch.equal(out, whole + it)
+        assert ptr == (g.send.data_ptr(), g.recv.data_ptr(), g.full.data_ptr())
+    res["grid"] = out.numpy().copy()
+    # (b) evenly divisible and nothing in front of the sharded dimension: the receive buffer is the result
+    g2 = sh.RowGatherer(6, tail=(2,))
+    lo2, hi2 = sh.shard_bounds(6, rank, world)
+    w2 = torch.arange(12, dtype=torch.float64).view(6, 2)
+    assert torch.equal(g2.gather(w2[lo2:hi2]), w2) and g2.full.data_ptr() == g2.recv.data_ptr()
+    # (c) the (draw x test point) tables of config 5: [2 M, S_local] blocks, draws LAST, 7 draws over 3 ranks; the
+    # rank computes straight into the send buffer when its share fills the slot
+    M, S = 3, 7
+    g3 = sh.RowGatherer(S, lead=(2 * M,))
+    lo3, hi3 = sh.shard_bounds(S, rank, world)
+    table = torch.arange(2 * M * S, dtype=torch.float64).view(2 * M, S)
+    if hi3 - lo3 == g3.slot:
+        g3.send.copy_(table[:, lo3:hi3])
+        got = g3.gather(None)
+    else:
+        got = g3.gather(table[:, lo3:hi3].contiguous())
+    assert torch.equal(got, table)
+    res["tables"] = got.numpy().copy()
+    np.savez(os.path.join(out_dir, "g%d.npz" % rank), **res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_preallocated_gatherer_three_ranks_ragged(tmp_path):
+    """shard.RowGatherer (what bench.py's timed step calls): one all_gather_into_tensor into buffers allocated once,
+    ragged shards, the sharded dimension first (likelihood vectors) or last (column-major prediction tables)."""
+    world = 3
+    mp.spawn(_gatherer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(tmp_path, "g%d.npz" % r)) for r in range(world)]
+    for k in ("grid", "tables"):
+        for o in outs[1:]:
+            np.testing.assert_array_equal(o[k], outs[0][k])

@@ -2,9 +2,11 @@
  * .Call() shim between R and libccgp (include/ccgp.h).
  *
  * NOT compiled against R in this repository's build: the build container has no R (no
- * Rinternals.h, no libR.so).  tests/test_r_shim_compiles.py compiles it against include/ccgp.h with a
- * minimal mock of the R headers (tests/r_mock/) -- a guard against prototype drift, nothing more.
- * A maintainer builds it on a machine with R and ROCm:
+ * Rinternals.h, no libR.so).  The test-suite compiles it against include/ccgp.h and a FUNCTIONAL mock of the
+ * R API (tests/r_mock/: typed vectors, dim / names, NA_REAL, PROTECT-stack and GC-hazard accounting, captured
+ * warnings, registered-routine dispatch) and executes every routine below on the GPU through that mock
+ * (tests/test_gpu_r_shim.py); under AddressSanitizer / ThreadSanitizer against a stub device library on the CPU
+ * (tests/test_host_sanitizers.py).  A maintainer builds it on a machine with R and ROCm:
  *
  *     R CMD SHLIB -o ccgpR.so r/ccgp_shim.c -I include \
  *         -L convex-combination-of-gaussian-processes_amd/csrc -lccgp
@@ -288,6 +290,12 @@ SEXP ccgp_R_set_kernel(SEXP family, SEXP nu) {
   return Rf_ScalarInteger(rc);
 }
 
+/* how many devices the batched calls are sharded over (1 = the single handle) */
+SEXP ccgp_R_devices(void) {
+  ccgp_multi* m = multi();
+  return Rf_ScalarInteger(m ? ccgp_multi_count(m) : 1);
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_corr_matrix", (DL_FUNC)&ccgp_R_corr_matrix, 2},
     {"ccgp_R_corr_cross", (DL_FUNC)&ccgp_R_corr_cross, 3},
@@ -303,6 +311,7 @@ static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_sigma2_mle", (DL_FUNC)&ccgp_R_sigma2_mle, 3},
     {"ccgp_R_mixed_logdet_designs", (DL_FUNC)&ccgp_R_mixed_logdet_designs, 5},
     {"ccgp_R_set_kernel", (DL_FUNC)&ccgp_R_set_kernel, 2},
+    {"ccgp_R_devices", (DL_FUNC)&ccgp_R_devices, 0},
     {NULL, NULL, 0}};
 
 void R_init_ccgpR(DllInfo* dll) {
@@ -314,4 +323,5 @@ void R_unload_ccgpR(DllInfo* dll) {
   (void)dll;
   if (g_handle) { ccgp_destroy(g_handle); g_handle = NULL; }
   if (g_multi) { ccgp_multi_destroy(g_multi); g_multi = NULL; }
+  g_multi_tried = 0;   /* CCGP_DEVICES is read again after a reload */
 }

@@ -1,4 +1,4 @@
-/* MOCK of <R_ext/Rdynload.h> -- see ../R.h. */
+/* FUNCTIONAL MOCK of <R_ext/Rdynload.h> -- see ../Rinternals.h. */
 #ifndef CCGP_MOCK_RDYNLOAD_H
 #define CCGP_MOCK_RDYNLOAD_H
 typedef void* (*DL_FUNC)(void);

@@ -1,0 +1,258 @@
+"""r/ccgp_shim.c EXECUTED: every `.Call` routine of the R shim, dispatched through its own registration table, on the
+real libccgp.so, against a functional mock of the R C API (tests/r_mock/: there is no R in the container or on the
+GPU boxes).  One test per routine listed in INTEGRATION.md section 3.  What is checked for each: the results are the
+ones `api.Handle` (ctypes -> the same C ABI) returns, shapes / `dim` / list layout are what r/ccgp.R indexes, a NaN from
+the device becomes R's NA_real_, a negative return code becomes a warning plus NA (never an Rf_error out of a device
+call), and the mock's bookkeeping stays clean (PROTECT balance, nothing left unprotected across an allocation, no
+REAL() on a non-double).  Reference return shapes: `logpost` -> list(val, beta, R.Inv) (Heat Exchanger Emulator/Combined GP
+Heat Exchanger.R:441-466), `choose.hyperpars` -> list(pars, likelihoods) (:584-595), `predict.post` -> cbind(mean, var)
+(:655-673)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_gv, load_hyper, load_qian, synthetic_design
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "r_mock"))
+import rmock  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    os.environ.pop("CCGP_DEVICES", None)
+    r = rmock.MockR()
+    yield r
+    r.unload()
+
+
+@pytest.fixture(autouse=True)
+def clean(R):
+    R.reset()
+    yield
+    R.assert_clean()
+
+
+def iso_row(p, t1, t2, d):
+    return np.concatenate([[p, 1 - p], np.full(d, t1), np.full(d, t2)])
+
+
+def test_corr_matrix_and_cross(R, handle):
+    D, y, Dt, _ = load_qian()
+    th = np.array([0.3, 0.5, 0.7, 1.1])
+    got = R.dot_call("ccgp_R_corr_matrix", R.real(D), R.real(th))
+    assert got.shape == (64, 64) and np.array_equal(got, handle.corr_matrix(D, th))
+    got = R.dot_call("ccgp_R_corr_cross", R.real(Dt), R.real(D), R.real(th))
+    assert got.shape == (14, 64) and np.array_equal(got, handle.corr_cross(Dt, D, th))
+    # corr.vec: x.new as a 1 x d matrix (r/ccgp.R builds it with matrix(as.double(x), nrow = 1))
+    one = R.dot_call("ccgp_R_corr_cross", R.real(Dt[:1]), R.real(D), R.real(th))
+    assert one.shape == (1, 64) and np.array_equal(one[0], got[0])
+    assert R.warnings() == []
+
+
+def test_mixed_corr_matrix_and_cross(R, handle):
+    D, y, Dt, _ = load_qian()
+    row = iso_row(0.8, 0.3, 15.0, 4)
+    got = R.dot_call("ccgp_R_mixed_corr_matrix", R.real(D), R.integer(2), R.real(row))
+    assert np.array_equal(got, handle.mixed_corr_matrix(D, 2, row))
+    got = R.dot_call("ccgp_R_mixed_corr_cross", R.real(Dt), R.real(D), R.integer(2), R.real(row))
+    assert got.shape == (14, 64) and np.array_equal(got, handle.mixed_corr_cross(Dt, D, 2, row))
+
+
+def test_negative_return_code_is_a_warning_and_na_not_an_error(R):
+    D, _, _, _ = load_qian()
+    got = R.dot_call("ccgp_R_mixed_corr_matrix", R.real(D), R.integer(9), R.real(np.ones(9 + 36)))   # K = 9 > 8
+    assert got.shape == (64, 64) and R.is_na(got).all()
+    w = R.warnings()
+    assert len(w) == 1 and "libccgp error -1" in w[0] and "bad argument" in w[0]
+
+
+def test_logpost_list_val_beta_rinv(R, handle):
+    from ccgp_amd import api
+    D, y, _, _ = load_qian()
+    s2 = float(np.var(y, ddof=1))
+    theta_t = np.array([np.log(0.3), np.log(15.0), np.log(4.0)])
+    pars = np.array([7.0, 3.0, 3.0, 28.0])
+    got = R.dot_call("ccgp_R_logpost", R.real(D), R.real(theta_t), R.real(y), R.real(s2), R.integer(api.PRIOR_INVGAMMA),
+                     R.real(pars))
+    assert list(got) == ["val", "beta", "R.Inv", "loglik"]            # r/ccgp.R reads r$val, r$beta, r$R.Inv, r$loglik
+    want = handle.logpost(D, y, s2, api.PRIOR_INVGAMMA, theta_t, pars)
+    assert got["val"][0] == want["val"] and got["beta"][0] == want["beta"] and got["loglik"][0] == want["loglik"]
+    assert got["R.Inv"].shape == (64, 64) and np.array_equal(got["R.Inv"], want["R_inv"])
+    # scripts whose logpost takes no prior parameters pass NULL (GV:429-454)
+    got = R.dot_call("ccgp_R_logpost", R.real(D), R.real(theta_t), R.real(y), R.real(s2), R.integer(api.PRIOR_GV), R.null())
+    assert got["val"][0] == handle.logpost(D, y, s2, api.PRIOR_GV, theta_t)["val"]
+    assert R.warnings() == []
+
+
+def test_logpost_singular_design_gives_na_like_try_solve(R):
+    """try(solve(R), silent = TRUE) -> R.Inv <- NA (HX:454-455).  psi = -800 -> theta = exp(psi) = 0 for both
+    components: R is the all-ones matrix, exactly singular (second pivot 1 - 1 = 0)."""
+    from ccgp_amd import api
+    D = np.array([[0.1, 0.2], [0.3, 0.8], [0.7, 0.9], [0.4, 0.5]])
+    y = np.array([1.0, 2.0, 3.0, 4.0])
+    got = R.dot_call("ccgp_R_logpost", R.real(D), R.real([-800.0, -800.0, 0.0]), R.real(y), R.real(1.0),
+                     R.integer(api.PRIOR_ISO), R.null())
+    assert R.is_na(got["val"]).all() and R.is_na(got["beta"]).all() and R.is_na(got["loglik"]).all()
+    assert got["R.Inv"].dtype == np.int32 and got["R.Inv"].shape == (1,) and got["R.Inv"][0] == -2 ** 31   # logical NA
+    assert R.warnings() == []            # a failed factorisation is a result, not an error
+
+
+def test_loglik_batch_nan_becomes_na(R, handle):
+    from ccgp_amd import api
+    D, y, _, _ = load_qian()
+    rng = np.random.default_rng(3)
+    P = np.array([iso_row(rng.uniform(0.5, 0.9), rng.uniform(0.2, 1), rng.uniform(5, 30), 4) for _ in range(37)])
+    got = R.dot_call("ccgp_R_loglik_batch", R.real(D), R.real(y), R.integer(2), R.real(P), R.real(37.0),
+                     R.integer(api.MEAN_ZERO_PLUS_TAU2), R.real(2500.0))
+    ll, beta, st = handle.loglik_batch(D, y, 2, P, 37.0, api.MEAN_ZERO_PLUS_TAU2, 2500.0)
+    assert np.array_equal(got[0], ll) and np.array_equal(got[1], beta) and np.array_equal(got[2], st)
+    assert got[2].dtype == np.int32
+    # theta = 0 in both components: R = 11', exactly singular -> NA_real_ (not a bare NaN), status = 2, no warning;
+    # the other draws of the batch are untouched
+    Pz = P[:5].copy()
+    Pz[1, 2:] = 0.0
+    Pz[4, 2:] = 0.0
+    got = R.dot_call("ccgp_R_loglik_batch", R.real(D), R.real(y), R.integer(2), R.real(Pz), R.real(37.0),
+                     R.integer(api.MEAN_PROFILE_BETA), R.real(0.0))
+    assert list(R.is_na(got[0])) == [False, True, False, False, True] and list(got[2]) == [0, 2, 0, 0, 2]
+    assert R.is_na(got[1])[[1, 4]].all() and np.array_equal(got[0][[0, 2, 3]], handle.loglik_batch(D, y, 2, Pz[[0, 2, 3]], 37.0)[0])
+    assert R.warnings() == []
+    # an invalid call (params with the wrong number of columns -> P != K + K d is not checkable in C; K = 0 is)
+    got = R.dot_call("ccgp_R_loglik_batch", R.real(D), R.real(y), R.integer(0), R.real(P[:5]), R.real(37.0),
+                     R.integer(0), R.real(0.0))
+    assert R.is_na(got[0]).all() and len(R.warnings()) == 1
+
+
+def test_grid_marginal_is_choose_hyperpars(R, handle):
+    D, y, _, _ = load_qian()
+    H = load_hyper("hx")[280:300]
+    got = R.dot_call("ccgp_R_grid_marginal", R.real(D), R.real(y), R.real(62.0), R.real(H), R.integer(1000), R.real(50.0),
+                     R.integer(1), R.real(-1.0))
+    vals, arg = handle.grid_marginal(D, y, 62.0, H, 1000, 50.0, True)
+    assert np.array_equal(got[0], vals)
+    assert int(got[1][0]) == arg + 1 == 13          # which.max is 1-based: row 293 of the full table (HX:774-775)
+    # likeli.hyperpars: a single quadruplet as a 1 x 4 matrix, no log (ADV:595)
+    one = R.dot_call("ccgp_R_grid_marginal", R.real(D), R.real(y), R.real(62.0), R.real(H[12:13]), R.integer(1000),
+                     R.real(50.0), R.integer(0), R.real(-1.0))
+    assert one[0].shape == (1,) and one[0][0] == pytest.approx(np.exp(vals[12]), rel=1e-12)
+    # a non-positive hyperparameter: warning + NA
+    bad = H[:3].copy()
+    bad[1, 2] = -1.0
+    got = R.dot_call("ccgp_R_grid_marginal", R.real(D), R.real(y), R.real(62.0), R.real(bad), R.integer(100), R.real(50.0),
+                     R.integer(1), R.real(-1.0))
+    assert R.is_na(got[0]).all() and "must be positive" in R.warnings()[0]
+
+
+def test_predict_batch_tables(R, handle):
+    D, y, Dt, _ = load_gv(50)
+    P = np.array([iso_row(0.7, 0.3, 15.0, 9), iso_row(0.9, 0.25, 20.0, 9), iso_row(0.6, 0.4, 12.0, 9)])
+    got = R.dot_call("ccgp_R_predict_batch", R.real(D), R.real(y), R.integer(2), R.real(P), R.real(Dt), R.real(10.0))
+    mean, var, beta, _ = handle.predict_batch(D, y, 2, P, Dt, 10.0)
+    assert got[0].shape == (3, 150) and np.array_equal(got[0], mean) and np.array_equal(got[1], var)
+    assert np.array_equal(got[2], beta)
+
+
+def test_literal_predict_post_factors_beta_sigma2(R, handle):
+    """factors (HX:604-613), predict.post's arithmetic (HX:667-670) -> cbind(mean, var), beta.MLE, sigma2.MLE."""
+    from ccgp_amd import api
+    D, y, Dt, _ = load_qian()
+    s2 = 40.0
+    lp = handle.logpost(D, y, s2, api.PRIOR_ISO, [np.log(0.3), np.log(15.0), np.log(4.0)])
+    Rinv, beta = lp["R_inv"], lp["beta"]
+    f = R.dot_call("ccgp_R_factors", R.real(Rinv), R.real(beta), R.real(y))
+    want = handle.factors(Rinv, beta, y)
+    assert f.shape == (2 * 64 + 1,) and np.array_equal(f, want)
+    row = iso_row(0.8, 0.3, 15.0, 4)
+    r = handle.mixed_corr_cross(Dt, D, 2, row)
+    got = R.dot_call("ccgp_R_predict_from_factors", R.real(r), R.real(beta), R.real(f[:64]), R.real(f[64:128]),
+                     R.real(f[128]), R.real(Rinv), R.real(s2))
+    m, v = handle.predict_from_factors(r, beta, f[:64], f[64:128], f[128], Rinv, s2)
+    assert got.shape == (14, 2) and np.array_equal(got[:, 0], m) and np.array_equal(got[:, 1], v)
+    b = R.dot_call("ccgp_R_beta_mle", R.real(Rinv), R.real(y))
+    assert b.shape == (1,) and b[0] == handle.beta_mle(Rinv, y)
+    s = R.dot_call("ccgp_R_sigma2_mle", R.real(Rinv), R.real(y), R.real(beta))
+    assert s[0] == handle.sigma2_mle(Rinv, y, beta)
+
+
+def test_mixed_logdet_designs(R, handle):
+    rng = np.random.default_rng(11)
+    designs = rng.random((6, 14, 2))
+    row = iso_row(0.8, 1.0, 12.0, 2)
+    Xs = np.stack([np.asfortranarray(Dd).ravel(order="F") for Dd in designs], axis=1)      # n*d x B, as r/ccgp.R passes it
+    got = R.dot_call("ccgp_R_mixed_logdet_designs", R.real(Xs), R.integer(14), R.integer(2), R.integer(2), R.real(row))
+    want, _ = handle.mixed_logdet_designs(designs, 2, row)
+    assert np.array_equal(got, want)
+
+
+def test_set_kernel_switches_the_family_for_later_calls(R, handle):
+    from ccgp_amd import api
+    X = np.linspace(0.05, 0.95, 8)[:, None]
+    rc = R.dot_call("ccgp_R_set_kernel", R.integer(api.KERNEL_MATERN), R.real(5.0))
+    assert rc[0] == 0
+    got = R.dot_call("ccgp_R_corr_matrix", R.real(X), R.real([0.4]))
+    handle.set_kernel(api.KERNEL_MATERN, 5.0)
+    try:
+        want = handle.corr_matrix(X, [0.4])
+    finally:
+        handle.set_kernel(api.KERNEL_GAUSS)
+    assert np.array_equal(got, want)
+    assert R.dot_call("ccgp_R_set_kernel", R.integer(0), R.real(0.0))[0] == 0
+    assert np.array_equal(R.dot_call("ccgp_R_corr_matrix", R.real(X), R.real([0.4])), handle.corr_matrix(X, [0.4]))
+    # nu outside the validated range: return code + warning, family unchanged
+    assert R.dot_call("ccgp_R_set_kernel", R.integer(1), R.real(50.0))[0] == -1 and len(R.warnings()) == 1
+
+
+def test_dispatch_goes_through_the_registration(R):
+    src = open(os.path.join(ROOT, "r", "ccgp_shim.c")).read()
+    import re
+    table = dict((n, int(k)) for n, k in re.findall(r'\{"(ccgp_R_\w+)", \(DL_FUNC\)&\w+, (\d+)\}', src))
+    assert R.routines == table and R.L.rmock_dynamic_symbols() == 0
+    with pytest.raises(rmock.RError, match="Incorrect number of arguments"):
+        R.dot_call("ccgp_R_beta_mle", R.real(np.eye(2)))
+    with pytest.raises(rmock.RError, match="not available"):
+        R.dot_call("ccgp_loglik_batch")
+    assert R.dot_call("ccgp_R_devices")[0] == 1
+
+
+def test_ccgp_devices_routes_the_batched_calls_through_ccgp_multi(R, handle):
+    """CCGP_DEVICES: the shim shards the batched calls over several devices (one-GPU box: device 0 listed twice --
+    shards then share it; distinct devices are the driver's 8-GPU run).  Same bits as the single handle."""
+    from ccgp_amd import api
+    D, y, Dt, _ = load_gv(90)
+    rng = np.random.default_rng(5)
+    P = np.array([iso_row(rng.uniform(0.5, 0.9), rng.uniform(0.2, 0.5), rng.uniform(10, 20), 9) for _ in range(11)])
+    H = load_hyper("hx")[:7]
+    Dq, yq, _, _ = load_qian()
+    R.unload()
+    os.environ["CCGP_DEVICES"] = "0,0"
+    try:
+        R.L.rmock_load()
+        assert R.dot_call("ccgp_R_devices")[0] == 2
+        got = R.dot_call("ccgp_R_loglik_batch", R.real(D), R.real(y), R.integer(2), R.real(P), R.real(10.0), R.integer(0),
+                         R.real(0.0))
+        ll, beta, st = handle.loglik_batch(D, y, 2, P, 10.0)
+        assert np.array_equal(got[0], ll) and np.array_equal(got[1], beta)
+        got = R.dot_call("ccgp_R_predict_batch", R.real(D), R.real(y), R.integer(2), R.real(P), R.real(Dt[:20]), R.real(10.0))
+        mean, var, b2, _ = handle.predict_batch(D, y, 2, P, Dt[:20], 10.0)
+        assert np.array_equal(got[0], mean) and np.array_equal(got[1], var) and np.array_equal(got[2], b2)
+        got = R.dot_call("ccgp_R_grid_marginal", R.real(Dq), R.real(yq), R.real(62.0), R.real(H), R.integer(200), R.real(50.0),
+                         R.integer(1), R.real(-1.0))
+        vals, arg = handle.grid_marginal(Dq, yq, 62.0, H, 200, 50.0, True)
+        assert np.array_equal(got[0], vals) and got[1][0] == arg + 1
+        # the family switch reaches every shard
+        assert R.dot_call("ccgp_R_set_kernel", R.integer(0), R.real(0.0))[0] == 0
+        assert R.warnings() == []
+        # a device that does not exist: warning, and the calls fall back to the single handle
+        R.unload()
+        os.environ["CCGP_DEVICES"] = "0,63"
+        R.L.rmock_load()
+        assert R.dot_call("ccgp_R_devices")[0] == 1
+        assert any("could not be opened" in w for w in R.warnings())
+    finally:
+        R.unload()
+        os.environ.pop("CCGP_DEVICES", None)
+        R.L.rmock_load()

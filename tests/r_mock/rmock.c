@@ -281,6 +281,9 @@ SEXP rmock_dot_call(const char* name, int nargs, SEXP* a) {
   }
   harness_mode = 1;
   error_jmp = NULL;
+  /* the value of the call now belongs to the caller (in R: bound to a variable, hence reachable); what the call
+   * left behind unreferenced is garbage, not a hazard for LATER calls */
+  for (SEXP o = all_objects; o; o = o->next) o->input = 1;
   return r;
 }
 

@@ -64,6 +64,7 @@ struct GemmArgs {
   double* logdet_part;
   int* status;
   int n;
+  double ptol;   // pivot_tolerance(mean_mode) for the fused diagonal factorisation
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
@@ -510,6 +511,7 @@ struct DiagArgs {
   int* status;          // indexed from b0
   int j, nt, nb, n;
   int ld;
+  double ptol;          // pivot_tolerance(mean_mode), ccgp_internal.h
 };
 
 // Register-resident: the 256 threads form a 16 x 16 grid (ty = row class, tx = column class)
@@ -554,7 +556,7 @@ __device__ __forceinline__ void diag_factor(const DiagArgs& g, int b, double* ld
       }
       __syncthreads();
       const double piv = colbuf[cur][k];
-      if (!(piv > 0.0)) { bad = k + 1; break; }   // uniform: every thread reads the same word
+      if (!(piv > g.ptol)) { bad = k + 1; break; }   // uniform: every thread reads the same word
       // 1 / pivot by v_rcp_f64 + two Newton steps (full precision, a fifth of a division's instructions)
       double rinv = __builtin_amdgcn_rcp(piv);
       rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
@@ -652,7 +654,7 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
         // thread layout.  All waves of a workgroup share that L1, so workgroup scope is enough: __syncthreads is
         // release(workgroup) + s_barrier + acquire(workgroup) -- no L2 write-back, no cache invalidate
         __syncthreads();
-        DiagArgs dg{g.A, g.a_stride, g.npad, g.invd, g.invd_stride, g.logdet_part, g.status, g.j, g.nt, g.nb, g.n, g.ld};
+        DiagArgs dg{g.A, g.a_stride, g.npad, g.invd, g.invd_stride, g.logdet_part, g.status, g.j, g.nt, g.nb, g.n, g.ld, g.ptol};
         diag_factor(dg, b, smem);   // the staging LDS is free: the K loop ended on a barrier
       }
       return;
@@ -1037,6 +1039,8 @@ __global__ __launch_bounds__(256, 1) void rinv_tile_kernel(RinvArgs g) {
     double* th = al_b + kTile;         // [K][d]
     double* w2 = th + K * d;           // [K]
     double* part = w2 + K;             // [4][Pn]
+    double* etab = part + 4 * Pn;      // 2^(j/256) for exp_cov
+    exp_table_load(etab, tid, 256);
     for (int e = tid; e < K * d; e += 256) th[e] = g.params[gdraw + (size_t)(K + e) * g.ldp];
     if (tid < K) { const double w = g.params[gdraw + (size_t)tid * g.ldp]; w2[tid] = w * w; }
     for (int e = tid; e < d * kTile; e += 256) {
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(256, 1) void rinv_tile_kernel(RinvArgs g) {
             double sdot = 0.0;
             for (int k = 0; k < d; ++k) sdot = fma(xa[k * kTile + lr] * th[q * d + k], xb[k * kTile + lc], sdot);
             const double dist = (ua[q * kTile + lr] + ub[q * kTile + lc]) + (-2.0 * sdot);
-            const double v = acc[x][y][r] * exp_cov(-dist);
+            const double v = acc[x][y][r] * exp_cov(dist, etab);
             T[x][y][r] = v;
             gsum += v;
           }
@@ -1206,6 +1210,7 @@ struct GroupRun {
     dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;
+    dg.ptol = g.ptol = pivot_tolerance(mean_mode);
     force_s = h->opt_strips;   // ccgp_set_option(CCGP_OPT_UPDATE_STRIPS): 0 = pick_strips per launch
   }
 
@@ -1284,7 +1289,7 @@ struct GroupRun {
 
 // LDS scratch of the gradient contraction must fit the S = 1 staging area
 bool blocked_grad_supported(int d, int K) {
-  return sizeof(double) * ((size_t)(2 * d + 2 * K + 2) * kTile + (size_t)K * d + K + 4 * (K + K * d)) <=
+  return sizeof(double) * ((size_t)(2 * d + 2 * K + 2) * kTile + (size_t)K * d + K + 4 * (K + K * d) + kExpTableDoubles) <=
          gemm_lds_bytes<1>();
 }
 

@@ -33,7 +33,10 @@ int fail(ccgp_handle* h, int code, const std::string& msg) {
 #define CCGP_LAUNCH_CHECK()                                                         \
   do {                                                                              \
     CCGP_HIP(hipGetLastError());                                                    \
-    if (!ccgp::attr_error().empty()) return fail(h, CCGP_EHIP, ccgp::attr_error()); \
+    {                                                                               \
+      const std::string ae_ = ccgp::attr_error(h->device);                          \
+      if (!ae_.empty()) return fail(h, CCGP_EHIP, ae_);                             \
+    }                                                                               \
   } while (0)
 
 // the Matern / spline families exist for the 1-D scripts only
@@ -1098,6 +1101,8 @@ int ccgp_factor_batch(ccgp_handle* h, const double* X, int n, int d, const doubl
   const int P = K + K * d;
   const bool fused = h->fam.id == 0 && n <= kSmallMaxN && small_lds_bytes(n, d, 1) <= (size_t)kLdsBytes - 64;
   const int npad = round_up(n, kTile);
+  if (!fused && S > 65535)   // the draw index is a grid y / z dimension in cov_kernel, rhs_rows_kernel, ...
+    return fail(h, CCGP_EINVAL, "ccgp_factor_batch: at most 65535 factors per set on the blocked path (n > 128)");
   size_t head = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
                 Carver::al(sizeof(double) * (size_t)S * P) + 2 * Carver::al(sizeof(double) * S) +
                 Carver::al(sizeof(int) * (size_t)S);
@@ -1141,6 +1146,10 @@ int ccgp_factor_batch(ccgp_handle* h, const double* X, int n, int d, const doubl
     blocked_loglik(h, fs->X, n, d, fs->y, dv, 0, S, npad, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, fs->w, fs->ll,
                    fs->beta, fs->status);
     if (hipGetLastError() != hipSuccess) return bail(fail(h, CCGP_EHIP, "ccgp_factor_batch: launch failed"));
+    {
+      const std::string ae = ccgp::attr_error(h->device);
+      if (!ae.empty()) return bail(fail(h, CCGP_EHIP, ae));
+    }
   }
   std::vector<int> st(S);
   hipError_t e = hipSuccess;

@@ -4,12 +4,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/ccgp.h"
+#include "exp_table.h"
 
 namespace ccgp {
 
@@ -18,6 +20,19 @@ constexpr int kSmallMaxN = 128;  // n <= this goes to the fused in-LDS evaluator
 constexpr int kMaxD = 64;        // input dimensions supported by the covariance kernels
 constexpr int kMaxK = 8;         // component GPs per draw
 constexpr int kLdsBytes = 160 * 1024;
+
+// When does a factorisation "fail" (status != 0, NaN -- the reference's NA)?
+//   mean mode 1 (cond.like, HX:561-572): the reference only runs mnormt::dmnorm, whose chol() stops at a
+//     NON-POSITIVE pivot -> threshold 0.
+//   mean mode 0 (logpost, HX:454-460): the reference first calls solve(R), and base R's solve() refuses a matrix whose
+//     reciprocal condition number is below .Machine$double.eps ("system is computationally singular") -> R.Inv <- NA.
+//     The device has no condition estimate; it uses the necessary condition that comes for free: the correlation
+//     matrix has a unit diagonal, its smallest LDL' pivot d_min bounds the smallest eigenvalue from above, so
+//     d_min <= eps  =>  cond_2(R) >= 1 / eps.  A pivot <= DBL_EPSILON therefore fails the evaluation.  (Before round 3
+//     the threshold was 0 here too, and an exactly duplicated design point failed or "succeeded" with a pivot of
+//     +-1e-17 depending on the rounding of that one subtraction.)
+constexpr double kSolvePivotTol = 2.220446049250313e-16;
+__host__ __device__ inline double pivot_tolerance(int mean_mode) { return mean_mode == 0 ? kSolvePivotTol : 0.0; }
 
 // one timed launch group: events are recorded on the handle's stream and only read back
 // (hipEventElapsedTime) in ccgp_get_timing, so timing never synchronises the pipeline.
@@ -182,44 +197,57 @@ inline void once_per_device(unsigned long long& mask, F set_attributes) {
   mask |= bit;
 }
 
-// exp(x) for the covariance kernels (x = -theta-weighted squared distance, finite).  Same argument
-// reduction, same degree-11 polynomial and the same operation order as the device library's
-// exp(double), hence the same bits for every argument the kernels produce -- but the Horner chain is
-// written as explicit three-operand v_fma_f64.  hipcc turns `fma(r, p, c)` with a hoisted constant c
-// into v_mov_b64 + v_fmac_f64 (two-address form), and adds the overflow / underflow selects: 35 VALU
-// instructions per exp against 19 here, in kernels that are VALU-issue bound (PMC: 72 % VALU-busy,
-// 37 % of the instructions in exp).  Underflow goes through v_ldexp_f64 (gradual, then 0); the
-// result for x > 709 is not clamped to +inf (the kernels never exponentiate a positive distance).
-__device__ __forceinline__ double exp_cov(double x) {
+// exp(x) for the covariance kernels (x = -theta-weighted squared distance, x <= 0 up to rounding).
+//
+// Round 3: table-driven.  exp(x) = 2^m * T[j] * e^r with n = rint(x * 256 / ln 2) = 256 m + j, T[j] = 2^(j/256)
+// (256 correctly rounded doubles in LDS, exp_table.h) and |r| <= ln 2 / 512, where a degree-4 polynomial is enough
+// (truncation r^5 / 120 <= 4e-17).  n comes out of the "magic number" trick: t = fma(x, 256/ln2, 1.5 * 2^52) holds
+// n in the low dword of its mantissa (no v_rndne_f64, no v_cvt_i32_f64) and n as a double is t - 1.5 * 2^52.
+// 11 fp64 instructions (max, fma, add, 2 fma for r, 3 fma + mul + fma for T + T (e^r - 1), ldexp) plus 3 cheap
+// 32-bit ones and one LDS read, against 17 + 2 for the library routine's degree-11 polynomial that rounds 1 and 2
+// used (explicit three-operand v_fma_f64: hipcc's two-address v_fmac_f64 form needs a v_mov_b64 per step) -- in
+// kernels that are fp64-VALU-issue bound (PMC: cov_kernel 98 % CU-busy at 0.25 of the HBM peak; 3 x 19 of its 86
+// instructions per entry were exp).  Error: <= 1.3 ulp over 2 * 10^5 arguments in [-700, 0] against a 50-digit
+// exp (exact-FMA emulation; the library routine: < 1 ulp); tests hold 1e-13 on entries.
+// The argument is clamped at -1000 for the index computation only (the magic-number trick needs |n| < 2^31); r is
+// formed from the ORIGINAL x, so a NaN distance stays NaN, and v_ldexp_f64 underflows gradually to 0.
+static __device__ const unsigned long long kExpTableBits[256] = CCGP_EXP_TABLE_BITS;
+constexpr int kExpTableDoubles = 256;
+
+// cooperative copy of the table into LDS (call before a barrier that precedes the first exp_cov)
+__device__ __forceinline__ void exp_table_load(double* tab, int tid, int nthreads) {
+  for (int e = tid; e < kExpTableDoubles; e += nthreads) tab[e] = __longlong_as_double((long long)kExpTableBits[e]);
+}
+
+// exp(-dist): the negation rides on the source modifiers of the first two instructions that read it.  Constants
+// sit in SGPRs where the instruction has a single one (gfx9 VOP3: one constant-bus operand), so only 1.5 * 2^52 and
+// 1/6 occupy VGPR pairs.
+__device__ __forceinline__ double exp_cov(double dist, const double* tab) {
 #if !defined(__HIP_DEVICE_COMPILE__)
-  return exp(x);   // host pass of the same translation unit: never called
+  (void)tab;
+  return exp(-dist);   // host pass of the same translation unit: never called
 #else
-  const double kLog2e = __longlong_as_double(0x3ff71547652b82feLL);
-  const double kNegLn2Hi = __longlong_as_double(0xbfe62e42fefa39efLL);
-  const double kNegLn2Lo = __longlong_as_double(0xbc7abc9e3b39803fLL);
-  const double c11 = __longlong_as_double(0x3e5ade156a5dcb37LL), c10 = __longlong_as_double(0x3e928af3fca7ab0cLL),
-               c9 = __longlong_as_double(0x3ec71dee623fde64LL), c8 = __longlong_as_double(0x3efa01997c89e6b0LL),
-               c7 = __longlong_as_double(0x3f2a01a014761f6eLL), c6 = __longlong_as_double(0x3f56c16c1852b7b0LL),
-               c5 = __longlong_as_double(0x3f81111111122322LL), c4 = __longlong_as_double(0x3fa55555555502a1LL),
-               c3 = __longlong_as_double(0x3fc5555555555511LL), c2 = __longlong_as_double(0x3fe000000000000bLL);
-  const double n = __builtin_rint(x * kLog2e);
-  double r = __builtin_fma(kNegLn2Hi, n, x);
-  r = __builtin_fma(kNegLn2Lo, n, r);
-  double p;
-#define CCGP_FMA3(D, A, B, C) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(D) : "v"(A), "v"(B), "v"(C))
-  CCGP_FMA3(p, r, c11, c10);
-  CCGP_FMA3(p, r, p, c9);
-  CCGP_FMA3(p, r, p, c8);
-  CCGP_FMA3(p, r, p, c7);
-  CCGP_FMA3(p, r, p, c6);
-  CCGP_FMA3(p, r, p, c5);
-  CCGP_FMA3(p, r, p, c4);
-  CCGP_FMA3(p, r, p, c3);
-  CCGP_FMA3(p, r, p, c2);
-#undef CCGP_FMA3
-  p = __builtin_fma(r, p, 1.0);
-  p = __builtin_fma(r, p, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)n);
+  const double kScale = __longlong_as_double(0x40771547652b82feLL);     // 256 / ln 2
+  const double kNegCHi = __longlong_as_double(0xbf662e42fe000000LL);    // -(ln 2 / 256), 24 trailing zero bits: n * hi is exact
+  const double kNegCLo = __longlong_as_double(0xbd9f473de6af278fLL);
+  const double kMagic = 6755399441055744.0;                             // 1.5 * 2^52
+  const double c4 = __longlong_as_double(0x3fa5555555555555LL), c3 = __longlong_as_double(0x3fc5555555555555LL);
+  const double kFloor = -1000.0;
+  double xc, t, r, p;
+  asm("v_max_f64 %0, -%1, %2" : "=v"(xc) : "v"(dist), "s"(kFloor));    // no canonicalising second v_max
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t) : "v"(xc), "s"(kScale), "v"(kMagic));
+  const double nf = t - kMagic;
+  const int n = __double2loint(t);
+  asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(r) : "s"(kNegCHi), "v"(nf), "v"(dist));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(kNegCLo), "v"(nf), "v"(r));
+  const double tj = tab[n & 255];
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "s"(c4), "v"(c3));
+  asm("v_fma_f64 %0, %1, %2, 0.5" : "=v"(p) : "v"(r), "v"(p));
+  asm("v_fma_f64 %0, %1, %2, 1.0" : "=v"(p) : "v"(r), "v"(p));
+  const double q = r * p;                                               // e^r - 1
+  double v;
+  asm("v_fma_f64 %0, %1, %2, %1" : "=v"(v) : "v"(tj), "v"(q));         // T + T (e^r - 1)
+  return __builtin_amdgcn_ldexp(v, n >> 8);
 #endif
 }
 
@@ -264,24 +292,40 @@ __device__ inline double matern_corr(const KernelFamily& f, double z2) {
   }
   return exp(f.nu * log(z) - z) * hs * s * f.norm;
 }
-__device__ __forceinline__ double corr_of_dist(const KernelFamily& f, double dist, int component = 0) {
-  if (f.id == 0) return exp_cov(-dist);
+__device__ __forceinline__ double corr_of_dist(const KernelFamily& f, double dist, const double* tab, int component = 0) {
+  if (f.id == 0) return exp_cov(dist, tab);
   if (f.id == 2 && component == 1) return spline_corr(dist);
   return matern_corr(f, dist);
 }
 
-// Raise a kernel's dynamic-LDS ceiling to the 160 KiB of a gfx950 CU.  A refusal is remembered (first
-// one wins) and reported by the next C-ABI call's launch check instead of surfacing later as an opaque
-// launch failure.
-inline std::string& attr_error() {
-  static std::string e;
+// Raise a kernel's dynamic-LDS ceiling to the 160 KiB of a gfx950 CU.  A refusal is remembered PER DEVICE (first one
+// wins) and reported by that device's next C-ABI call's launch check instead of surfacing later as an opaque launch
+// failure.  raise_lds_limit runs inside once_per_device's lambda, i.e. with attr_mutex held; readers (shard threads of
+// ccgp_multi among them) look at an atomic mask first and take the mutex only when their device has an entry.
+inline std::string* attr_errors() {
+  static std::string e[64];
   return e;
+}
+inline std::atomic<unsigned long long>& attr_error_mask() {
+  static std::atomic<unsigned long long> m{0};
+  return m;
 }
 inline void raise_lds_limit(const void* kernel, const char* name) {
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 64);
-  if (e != hipSuccess && attr_error().empty())
-    attr_error() = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for ") + name + ": " +
-                   hipGetErrorString(e);
+  if (e == hipSuccess) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::string& slot = attr_errors()[dev & 63];
+  if (slot.empty()) {
+    slot = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for ") + name + ": " + hipGetErrorString(e);
+    attr_error_mask().fetch_or(1ull << (dev & 63));
+  }
+}
+// empty when every attribute request on `device` went through
+inline std::string attr_error(int device) {
+  if (!(attr_error_mask().load() & (1ull << (device & 63)))) return std::string();
+  std::lock_guard<std::mutex> guard(attr_mutex());
+  return attr_errors()[device & 63];
 }
 
 struct ScopedTimer {

@@ -38,13 +38,14 @@ struct CovArgs {
   int raw_mix;      // 1: sum w_c^2 r_c without the division by sum w_c^2 (corr.vec.combined as written, D1F:470-480)
 };
 
-// LDS: xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
+// LDS: etab[256] | xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
 // FAM = 0: Gaussian (the hot instantiation: nothing of the Matern code in it); FAM = 1: Matern (D1:348-351)
 template <int FAM>
 __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int d = a.d, K = a.K;
-  double* xa = smem;
+  double* etab = smem;                 // 2^(j/256) for exp_cov
+  double* xa = etab + kExpTableDoubles;
   double* xb = xa + d * kCovRows;
   double* ua = xb + d * kCovCols;
   double* ub = ua + K * kCovRows;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int i0 = tr * kCovRows, j0 = tc * kCovCols;
 
+  if (FAM == 0) exp_table_load(etab, tid, 256);
   for (int e = tid; e < K * d; e += 256) th[e] = FAM == 0 ? a.params[b + (size_t)(K + e) * a.ldp] : theta_to_rate(a.fam, a.params[b + (size_t)(K + e) * a.ldp], e / d);
   if (tid < K) {
     double w = a.params[b + (size_t)tid * a.ldp];
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
       const double dist = (ur + ub[c * kCovCols + jl0 + jj]) + (-2.0 * sdot[jj]);
-      accs[jj] = fma(wc, (FAM == 0 ? exp_cov(-dist) : corr_of_dist(a.fam, dist, c)), accs[jj]);
+      accs[jj] = fma(wc, (FAM == 0 ? exp_cov(dist, etab) : corr_of_dist(a.fam, dist, etab, c)), accs[jj]);
     }
   }
 #pragma unroll
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
 }
 
 size_t cov_lds(int d, int K) {
-  return sizeof(double) * (size_t)(2 * d * 64 + 2 * K * 64 + K * d + K);
+  return sizeof(double) * (size_t)(kExpTableDoubles + 2 * d * 64 + 2 * K * 64 + K * d + K);
 }
 
 // d = 64, K = 8 needs 78 KiB: above the 64 KiB a kernel gets without asking

@@ -17,6 +17,7 @@
 // points block, and the grid entry point does its quantile work on the host, which the threads also
 // spread over cores).  A handle is touched by exactly one thread at a time; no R API is called here.
 #include <algorithm>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -46,6 +47,8 @@ std::vector<double> pack_rows(const double* a, int rows, int cols, int lo, int h
   return out;
 }
 
+constexpr int kShardNoMemory = -1000, kShardException = -1001;   // internal: never returned to the caller
+
 // run fn(shard) on every shard concurrently; collect return codes
 template <class F>
 int run_shards(ccgp_multi* m, int total, F fn) {
@@ -56,11 +59,25 @@ int run_shards(ccgp_multi* m, int total, F fn) {
     int lo, hi;
     bounds(total, r, w, &lo, &hi);
     if (hi == lo) continue;
-    th.emplace_back([&, r, lo, hi] { rc[r] = fn(r, lo, hi); });
+    // an exception in the thread body (std::bad_alloc while packing the shard's rows, ...) would otherwise end in
+    // std::terminate -- inside R, that is the user's session
+    th.emplace_back([&, r, lo, hi] {
+      try {
+        rc[r] = fn(r, lo, hi);
+      } catch (const std::bad_alloc&) {
+        rc[r] = kShardNoMemory;
+      } catch (...) {
+        rc[r] = kShardException;
+      }
+    });
   }
   for (auto& t : th) t.join();
   int bad = 0;
   for (int r = 0; r < w; ++r) {
+    if (rc[r] == kShardNoMemory || rc[r] == kShardException) {
+      m->err = "shard " + std::to_string(r) + (rc[r] == kShardNoMemory ? ": host memory exhausted" : ": exception in the shard thread");
+      return rc[r] == kShardNoMemory ? CCGP_ENOMEM : CCGP_EHIP;
+    }
     if (rc[r] < 0) {
       m->err = "shard " + std::to_string(r) + ": " + ccgp_last_error(m->h[r]);
       return rc[r];

@@ -59,7 +59,7 @@ __device__ inline double wave_sum(double v) {
   return __shfl(v, 0, 64);
 }
 
-// LDS carve (doubles):  A[ld*n] | xs[d*n] | us[K*n] | xt[d*mtile] | ut[K*mtile] | th[K*d] | w2[K] | red[16]
+// LDS carve (doubles):  A[ld*n] | xs[d*n] | us[K*n] | xt[d*mtile] | ut[K*mtile] | th[K*d] | w2[K] | red[16] | etab[256]
 __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int n = a.n, d = a.d, K = a.K;
@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
   double* th = ut + K * a.mtile;
   double* w2 = th + K * d;
   double* red = w2 + K;
+  double* etab = red + 16;   // 2^(j/256) for exp_cov
 
+  exp_table_load(etab, tid, 256);
   for (int e = tid; e < K * d; e += 256) th[e] = a.params[b + (size_t)(K + e) * a.ldp];
   if (tid < K) {
     double w = a.params[b + (size_t)tid * a.ldp];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           double s = 0.0;
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + i] * th[c * d + k], xs[k * n + j], s);
           double dist = (us[c * n + i] + us[c * n + j]) + (-2.0 * s);
-          acc += w2[c] * exp_cov(-dist);
+          acc += w2[c] * exp_cov(dist, etab);
         }
         v = post_scale * (acc / sw) + post_shift;
       } else if (i == n) {
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + j] * th[c * d + k], xt[k * a.mtile + t], s);
           // corr.vec order: (theta'x^2 - 2 X Theta x) + u_i   (HX:373)
           double dist = (ut[c * a.mtile + t] - 2.0 * s) + us[c * n + j];
-          acc += w2[c] * exp_cov(-dist);
+          acc += w2[c] * exp_cov(dist, etab);
         }
         v = acc / sw;
       } else {
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
   for (int k = 0; k < n; ++k) {
     __syncthreads();
     const double piv = A[k + (size_t)k * ld];
-    if (!(piv > 0.0)) { bad = k + 1; break; }   // uniform: every thread reads the same word
+    if (!(piv > pivot_tolerance(a.mode))) { bad = k + 1; break; }   // uniform: every thread reads the same word
     const double rinv = 1.0 / piv;
     const double* colk = A + (size_t)k * ld;
     for (int j = k + 1 + wave; j < n; j += 4) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           double s = 0.0;
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + i] * th[c * d + k], xs[k * n + jt], s);
           double dist = (us[c * n + i] + us[c * n + jt]) + (-2.0 * s);
-          double rc = exp_cov(-dist);
+          double rc = exp_cov(dist, etab);
           if (kk >= 0) { double df = xs[kk * n + i] - xs[kk * n + jt]; rc *= df * df; }
           acc = fma(Mit, rc, acc);
         }
@@ -304,7 +306,7 @@ __global__ void grad_reduce_kernel(const double* gpart, int nchunks, int P, int 
 
 size_t small_lds_bytes(int n, int d, int mtile) {
   size_t dbl = (size_t)(n + 2 + mtile) * n + (size_t)d * n + (size_t)kMaxK * n +
-               (size_t)d * mtile + (size_t)kMaxK * mtile + (size_t)kMaxK * d + kMaxK + 16;
+               (size_t)d * mtile + (size_t)kMaxK * mtile + (size_t)kMaxK * d + kMaxK + 16 + kExpTableDoubles;
   return dbl * sizeof(double);
 }
 

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
   const bool valid = b < a.draw0 + a.B;
   if (!valid) b = a.draw0 + a.B - 1;   // keep the wave alive (shared loads, barriers); results discarded
 
-  double* xs = smem;                          // d x n, shared by the matrices of this workgroup
+  double* etab = smem;                        // 2^(j/256) for exp_cov, shared by the workgroup
+  double* xs = etab + kExpTableDoubles;       // d x n, shared by the matrices of this workgroup
   double* mine = xs + d * n + (size_t)sub * PM;
   double* us = mine;
   double* th = us + kMaxK * NP;
@@ -99,14 +100,15 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
   double* ut = zb + 2 * NP + 8;               // [K][XR]   (NE > 1)
   double* psum = ut + kMaxK * XR;             // [3][XR][G] (NE > 1)
   const int t0 = blockIdx.y * MT;             // first test site of this chunk
-  double* xt = smem + (size_t)d * n + (size_t)MPW * PM;   // [d][XR], shared by the workgroup (NE > 1)
+  double* xt = xs + (size_t)d * n + (size_t)MPW * PM;     // [d][XR], shared by the workgroup (NE > 1)
 
   const int pb = a.shared_params ? 0 : b;
+  exp_table_load(etab, tid, 256);
   if (a.x_stride == 0) {
     for (int e = tid; e < n * d; e += 256) xs[e] = a.X[e];
   } else {
     // per-evaluation designs: each matrix keeps its own copy right behind the shared slot
-    xs = smem + (size_t)d * n + (size_t)MPW * PM + (size_t)sub * d * n;   // (never combined with NE > 1)
+    xs = xs + (size_t)d * n + (size_t)MPW * PM + (size_t)sub * d * n;     // (never combined with NE > 1)
     for (int e = lt; e < n * d; e += TPM) xs[e] = a.X[(size_t)b * a.x_stride + e];
   }
   for (int e = lt; e < K * d; e += TPM) th[e] = a.params[pb + (size_t)(K + e) * a.ldp];
@@ -198,13 +200,13 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
             // every (r, c) is a matrix entry; entries above the diagonal of the diagonal blocks (aa == bb, ty < tx)
             // are computed too and zeroed below -- cheaper than a divergent branch
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
-            M[aa][bb] = fma(wq, exp_cov(-dist), M[aa][bb]);
+            M[aa][bb] = fma(wq, exp_cov(dist, etab), M[aa][bb]);
             // pin the finished entry here: without the branch the compiler sinks the tail of every exp (ldexp + mix)
             // to the end of the component loop and keeps two temporaries per entry alive until then (580 B of scratch)
             asm volatile("" : "+v"(M[aa][bb]));
           } else if (r < n && c < n && r >= c) {
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
-            M[aa][bb] = fma(wq, exp_cov(-dist), M[aa][bb]);
+            M[aa][bb] = fma(wq, exp_cov(dist, etab), M[aa][bb]);
           }
         }
       }
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
             double sd = 0.0;
             for (int k = 0; k < d; ++k) sd = fma(xs[k * n + c] * th[q * d + k], xt[k * XR + ridx], sd);
             const double dist = (ut[q * XR + ridx] - 2.0 * sd) + us[q * NP + c];
-            acc = fma(w2[q], exp_cov(-dist), acc);
+            acc = fma(w2[q], exp_cov(dist, etab), acc);
           }
           v = acc / sw;
         }
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
 
   // ---- L' D L'^T on registers; one column broadcast through LDS per step ------------------------
   int bad = 0, cur = 0;
+  // a bare log-determinant (entropy criteria, BSQ:856-877: the reference calls det(), nothing can "fail") keeps 0
+  const double ptol = a.logdet ? 0.0 : pivot_tolerance(a.mode);
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll 1
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
       }
       mat_sync<G>();
       const double piv = cb[k];
-      if (!(piv > 0.0)) { bad = k + 1; break; }   // uniform over the matrix's threads
+      if (!(piv > ptol)) { bad = k + 1; break; }   // uniform over the matrix's threads (pivot_tolerance: ccgp_internal.h)
       // 1 / pivot by v_rcp_f64 + two Newton steps (full precision, ~6 instructions instead of ~30)
       double rinv = __builtin_amdgcn_rcp(piv);
       rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
 template <int G, int NB, int NE>
 size_t reg_lds_bytes(const RegArgs& a) {
   constexpr int MPW = 256 / (G * G);
-  return sizeof(double) * ((size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G, NE) +
+  return sizeof(double) * (kExpTableDoubles + (size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G, NE) +
                            (a.x_stride ? (size_t)MPW * a.d * a.n : 0) + (NE > 1 ? (size_t)a.d * G * NE : 0));
 }
 
@@ -433,7 +437,7 @@ bool small_reg_supported(int n, int d, bool per_design, bool predict) {
   const int NB = (n + G - 1) / G;
   const int MPW = 256 / (G * G);
   const int NE = predict ? kPredictNE : 1;
-  return sizeof(double) * ((size_t)d * n + (size_t)MPW * kPerMat(G * NB, G, NE) +
+  return sizeof(double) * (kExpTableDoubles + (size_t)d * n + (size_t)MPW * kPerMat(G * NB, G, NE) +
                            (per_design ? (size_t)MPW * d * n : 0) + (predict ? (size_t)d * G * NE : 0)) <=
          (size_t)kLdsBytes - 64;
 }

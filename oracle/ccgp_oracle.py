@@ -122,8 +122,19 @@ def sigma2_mle(R_inv, y, beta):
 
 # --------------------------------------------------------------------------- a12/a13
 def solve_inverse(R):
-    """base R solve(R) = LAPACK dgesv(R, I) (HX:454).  Raises on exact singularity."""
-    return np.linalg.inv(np.asarray(R, dtype=np.float64))
+    """base R solve(R) (HX:454) = solve.default(a, tol = .Machine$double.eps) -> La_solve: LAPACK dgesv(R, I), an error
+    for an exactly singular U ("system is exactly singular"), THEN rcond = dgecon("1", LU, ||R||_1) and an error when
+    rcond < tol ("system is computationally singular: reciprocal condition number = ...").  The reference wraps the
+    call in try() and maps either error to R.Inv <- NA (HX:454-455).  Base R is not in the reference tree; restated
+    from its documented behaviour (?solve: "tol: the tolerance for detecting linear dependencies in the columns of a")."""
+    A = np.asarray(R, dtype=np.float64)
+    x = np.linalg.inv(A)                      # dgesv(A, I); raises LinAlgError on an exactly singular U
+    lu, _, info = sla.lapack.dgetrf(A)        # the same factorisation again, for the condition estimate
+    anorm = np.abs(A).sum(axis=0).max()
+    rcond, info = sla.lapack.dgecon(lu, anorm, norm="1")
+    if not rcond >= np.finfo(np.float64).eps:
+        raise np.linalg.LinAlgError("system is computationally singular: reciprocal condition number = %g" % rcond)
+    return x
 
 
 def dmnorm_log(x, mean, varcov):

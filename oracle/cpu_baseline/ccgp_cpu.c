@@ -76,8 +76,10 @@ static void blas_restore(int prev) {
   if (g_setthr && prev > 0) g_setthr(prev);
 }
 
-/* plain blocked Cholesky (lower, column-major), used only when no LAPACK could be bound */
-static int chol_builtin(double* A, int n) {
+/* plain blocked Cholesky (lower, column-major), used only when no LAPACK could be bound.  ptol: a pivot <= ptol fails
+ * (0 for the grid likelihood, DBL_EPSILON for the profile-beta likelihood whose reference path calls solve(R), which
+ * refuses rcond < eps, HX:454 -- the same rule as the device, csrc/ccgp_internal.h pivot_tolerance) */
+static int chol_builtin(double* A, int n, double ptol) {
   const int NB = 64;
   for (int j0 = 0; j0 < n; j0 += NB) {
     const int jb = n - j0 < NB ? n - j0 : NB;
@@ -87,7 +89,7 @@ static int chol_builtin(double* A, int n) {
         for (int i = j; i < n; ++i) A[i + (size_t)j * n] -= A[i + (size_t)k * n] * l;
       }
       const double piv = A[j + (size_t)j * n];
-      if (!(piv > 0.0)) return j + 1;
+      if (!(piv > ptol)) return j + 1;
       const double s = sqrt(piv), rs = 1.0 / s;
       A[j + (size_t)j * n] = s;
       for (int i = j + 1; i < n; ++i) A[i + (size_t)j * n] *= rs;
@@ -114,13 +116,16 @@ static void fwd_builtin(const double* L, int n, double* x) {
  * (measured: 8 threads slower than 1 at n = 64), and a 64 x 64 factorisation needs no blocking */
 enum { kSmallN = 128 };
 
-static int factor(double* A, int n) {
+static int factor(double* A, int n, double ptol) {
   if (g_potrf && n > kSmallN) {
     int info = 0;
     g_potrf("L", &n, A, &n, &info);
+    if (info == 0 && ptol > 0.0)
+      for (int j = 0; j < n; ++j)
+        if (!(A[j + (size_t)j * n] * A[j + (size_t)j * n] > ptol)) return j + 1;
     return info;
   }
-  return chol_builtin(A, n);
+  return chol_builtin(A, n, ptol);
 }
 
 static void fwd(const double* L, int n, double* x) {
@@ -196,7 +201,7 @@ int ccgp_cpu_loglik_batch(const double* X, int n, int d, const double* y, int K,
       const double* row = params + b;
       const double cs = sigma2 * sum_w2(row, K, ldp);
       build_cov(X, n, d, K, row, ldp, mode == 1 ? cs : 1.0, mode == 1 ? tau2 : 0.0, A, u, xt);
-      const int info = factor(A, n);
+      const int info = factor(A, n, mode == 0 ? 2.220446049250313e-16 : 0.0);
       if (info != 0) {
         if (status) status[b] = info;
         out_ll[b] = NAN;
@@ -253,7 +258,7 @@ int ccgp_cpu_predict_batch(const double* X, int n, int d, const double* y, int K
       const double* row = params + s;
       const double sw = sum_w2(row, K, ldp);
       build_cov(X, n, d, K, row, ldp, 1.0, 0.0, A, u, xt);
-      if (factor(A, n) != 0) {
+      if (factor(A, n, 2.220446049250313e-16) != 0) {
         for (int t = 0; t < m; ++t) mean[s + (size_t)t * S] = var[s + (size_t)t * S] = NAN;
         ++bad;
         continue;

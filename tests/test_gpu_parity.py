@@ -55,6 +55,31 @@ def test_corr_kernels_qian(handle):
     np.testing.assert_allclose(C, want, rtol=1e-12)
 
 
+def test_device_exp_is_within_two_ulp_down_to_underflow(handle):
+    """exp_cov (ccgp_internal.h; round 3: 256-entry table x degree-4 polynomial) in isolation.  With the new site at the
+    origin the expanded distance of corr.vec (HX:373) is (0 - 2 * 0) + theta x_i^2, i.e. the correctly rounded product
+    itself, so the entry is exp(-fl(fl(x^2) theta)) and can be compared with a 50-digit exp of that very double:
+    <= 2 ulp over 20 000 arguments in [-745, 0] (gradual underflow included), exactly 1 at 0, exactly 0 beyond the
+    underflow threshold, NaN for a NaN coordinate."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    rng = np.random.default_rng(7)
+    x = np.sqrt(np.concatenate([rng.uniform(0, 1, 6000), rng.uniform(0, 40, 8000), rng.uniform(0, 745, 6000),
+                                [0.0, 750.0, 1000.0, 5000.0, 1e8]]))
+    theta = 1.0000001
+    r = handle.corr_cross(np.zeros((1, 1)), x[:, None], [theta])[0]
+    arg = -((x * x) * theta)
+    want = np.array([float(mp.exp(mp.mpf(float(a)))) for a in arg])
+    assert r[-5] == 1.0 and (r[-4:] == 0.0).all()
+    ok = want > 2.3e-308                       # normal range: relative ulp bound
+    assert np.max(np.abs(r[ok] - want[ok]) / np.spacing(want[ok])) <= 2.0
+    assert np.max(np.abs(r[~ok] - want[~ok])) <= 2 * 4.95e-324 * 2 ** 1    # denormals: within a couple of quanta
+    xn = x[:64].copy()
+    xn[5] = np.nan
+    rn = handle.corr_cross(np.zeros((1, 1)), xn[:, None], [theta])[0]
+    assert np.isnan(rn[5]) and np.isfinite(np.delete(rn, 5)).all()
+
+
 def test_corr_kernels_aniso(handle):
     from ccgp_amd.rsurface import CombinedGP
     gp = CombinedGP("ANI", handle=handle)

@@ -208,3 +208,21 @@ def test_two_family_script_restatement_and_fixture():
     for c in g["cases"]:
         lp = orc.logpost_2f(X, c["theta_t"], y, c["sigma2"], nu)
         assert lp["val"] == pytest.approx(c["val"], rel=1e-12)
+
+
+def test_solve_refuses_a_computationally_singular_matrix_like_base_r():
+    """solve(R) inside logpost (HX:454): base R's solve.default stops when rcond < .Machine$double.eps, the reference's
+    try() turns that into R.Inv <- NA.  A duplicated design point is singular only up to rounding (LU meets a pivot of
+    +-1e-17, not 0): without the rcond test the restatement would return a garbage inverse where R returns NA."""
+    from conftest import load_qian
+    D, y, _, _ = load_qian()
+    Dd = D.copy()
+    Dd[40] = Dd[3]
+    R = orc.mixed_corr_matrix_iso(Dd, 0.8, 0.3, 15.0)
+    with pytest.raises(np.linalg.LinAlgError, match="singular"):
+        orc.solve_inverse(R)
+    lp = orc.logpost(Dd, [math.log(0.3), math.log(15.0), math.log(4.0)], y, 10.0, "GV")
+    assert lp["R_inv"] is None and math.isnan(lp["val"])
+    # a well-conditioned matrix goes through and is the LAPACK inverse
+    R = orc.mixed_corr_matrix_iso(D, 0.8, 0.3, 15.0)
+    np.testing.assert_array_equal(orc.solve_inverse(R), np.linalg.inv(R))

@@ -64,7 +64,7 @@ struct GemmArgs {
   double* logdet_part;
   int* status;
   int n;
-  double ptol;   // pivot_tolerance(mean_mode) for the fused diagonal factorisation
+  double ptol;   // pivot_tolerance(mean_mode, n) for the fused diagonal factorisation
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
@@ -511,7 +511,7 @@ struct DiagArgs {
   int* status;          // indexed from b0
   int j, nt, nb, n;
   int ld;
-  double ptol;          // pivot_tolerance(mean_mode), ccgp_internal.h
+  double ptol;          // pivot_tolerance(mean_mode, n), ccgp_internal.h
 };
 
 // Register-resident: the 256 threads form a 16 x 16 grid (ty = row class, tx = column class)
@@ -1210,7 +1210,7 @@ struct GroupRun {
     dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;
-    dg.ptol = g.ptol = pivot_tolerance(mean_mode);
+    dg.ptol = g.ptol = pivot_tolerance(mean_mode, n);
     force_s = h->opt_strips;   // ccgp_set_option(CCGP_OPT_UPDATE_STRIPS): 0 = pick_strips per launch
   }
 

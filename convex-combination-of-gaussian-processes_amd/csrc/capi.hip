@@ -134,7 +134,7 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
   // the fused evaluators generate Gaussian correlations in registers; any other family goes through
   // the materialised-matrix (blocked) path, where only cov_kernel knows about families
   const bool gauss = dv.fam.id == 0;
-  const bool reg_ok = gauss && small_reg_supported(n, d) && !force_lds;
+  const bool reg_ok = gauss && small_reg_supported(n, d, K) && !force_lds;
   const bool lds_ok = gauss && n <= kSmallMaxN && small_lds_bytes(n, d, 0) <= (size_t)kLdsBytes - 64;
   if (reg_ok || lds_ok) {   // otherwise (n > 128, or d too large for LDS) the blocked path takes it
     ScopedTimer t(h, CCGP_T_FUSED);
@@ -848,7 +848,7 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
     return fail(h, CCGP_EINVAL, "ccgp_mixed_logdet_designs: bad argument");
   if (h->fam.id != 0)
     return fail(h, CCGP_EUNSUPPORTED, "ccgp_mixed_logdet_designs: Gaussian family only (BSQ:856-877)");
-  if (!small_reg_supported(n, d, true))
+  if (!small_reg_supported(n, d, K, true))
     return fail(h, CCGP_EUNSUPPORTED, "ccgp_mixed_logdet_designs: designs of more than 128 points (or too wide for LDS) not implemented");
   CCGP_HIP(hipSetDevice(h->device));
   const int P = K + K * d;
@@ -1021,7 +1021,7 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   {
     ScopedTimer t(h, CCGP_T_FUSED);
     const bool force_lds = h->opt_small_lds != 0;
-    if (small_reg_supported(n, d, false, true) && !force_lds)
+    if (small_reg_supported(n, d, K, false, true) && !force_lds)
       launch_small_reg_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
                                d_status);
     else

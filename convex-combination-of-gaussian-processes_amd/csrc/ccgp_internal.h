@@ -26,13 +26,20 @@ constexpr int kLdsBytes = 160 * 1024;
 //     NON-POSITIVE pivot -> threshold 0.
 //   mean mode 0 (logpost, HX:454-460): the reference first calls solve(R), and base R's solve() refuses a matrix whose
 //     reciprocal condition number is below .Machine$double.eps ("system is computationally singular") -> R.Inv <- NA.
-//     The device has no condition estimate; it uses the necessary condition that comes for free: the correlation
-//     matrix has a unit diagonal, its smallest LDL' pivot d_min bounds the smallest eigenvalue from above, so
-//     d_min <= eps  =>  cond_2(R) >= 1 / eps.  A pivot <= DBL_EPSILON therefore fails the evaluation.  (Before round 3
-//     the threshold was 0 here too, and an exactly duplicated design point failed or "succeeded" with a pivot of
-//     +-1e-17 depending on the rounding of that one subtraction.)
-constexpr double kSolvePivotTol = 2.220446049250313e-16;
-__host__ __device__ inline double pivot_tolerance(int mean_mode) { return mean_mode == 0 ? kSolvePivotTol : 0.0; }
+//     The device has no condition estimate; it uses a necessary condition that comes for free: the correlation
+//     matrix has a unit diagonal and its smallest LDL' pivot d_min bounds the smallest eigenvalue from above, so
+//     d_min <= n eps  =>  cond_2(R) >= 1 / (n eps), and the 1-norm condition number LAPACK estimates can be n times
+//     cond_2.  A pivot <= n * DBL_EPSILON therefore fails the evaluation.  (A threshold of eps alone is not enough: a
+//     duplicated design point leaves a pivot of the size of the rounding error of an n-term sum of squares -- the
+//     n = 300 matrix of tests/test_gpu_parity.py::test_non_positive_definite_maps_to_na passed a threshold of eps;
+//     before round 3 the threshold was 0 here too, and such a matrix failed or "succeeded" depending on the sign of
+//     that rounding error.)
+constexpr double kSolvePivotEps = 2.220446049250313e-16;
+__host__ __device__ inline double pivot_tolerance(int mean_mode, int n) { return mean_mode == 0 ? n * kSolvePivotEps : 0.0; }
+
+}  // namespace ccgp
+
+namespace ccgp {
 
 // one timed launch group: events are recorded on the handle's stream and only read back
 // (hipEventElapsedTime) in ccgp_get_timing, so timing never synchronises the pipeline.
@@ -118,7 +125,7 @@ void launch_small_grad(hipStream_t s, const double* X, int n, int d, const doubl
                        int* status, double* gpart);
 
 // ---- small_reg.hip: register-resident evaluator for the plain likelihood (n <= 128) ---------
-bool small_reg_supported(int n, int d, bool per_design = false, bool predict = false);
+bool small_reg_supported(int n, int d, int K, bool per_design = false, bool predict = false);
 void launch_small_reg_predict(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                               int S, const double* Xtest, int m, double sigma2, double* mean, double* var,
                               double* beta, int* status);
@@ -248,6 +255,58 @@ __device__ __forceinline__ double exp_cov(double dist, const double* tab) {
   double v;
   asm("v_fma_f64 %0, %1, %2, %1" : "=v"(v) : "v"(tj), "v"(q));         // T + T (e^r - 1)
   return __builtin_amdgcn_ldexp(v, n >> 8);
+#endif
+}
+
+// exp(-dist) WITHOUT a table: the device library's argument reduction and degree-11 polynomial as explicit
+// three-operand v_fma_f64 (rounds 1-2; same bits as the library's exp): 17 fp64 instructions + 2.  Kept for the
+// register-resident small-n evaluators, where the table variant measured no faster (round 3, profiles/r03/): their
+// waves already wait on LDS (column broadcasts of the elimination) and 65 data-dependent table reads per thread add
+// bank conflicts to that queue.
+__device__ __forceinline__ double exp_cov_poly(double dist) {
+  const double x = -dist;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return exp(x);   // host pass of the same translation unit: never called
+#else
+  const double kLog2e = __longlong_as_double(0x3ff71547652b82feLL);
+  const double kNegLn2Hi = __longlong_as_double(0xbfe62e42fefa39efLL);
+  const double kNegLn2Lo = __longlong_as_double(0xbc7abc9e3b39803fLL);
+  const double c11 = __longlong_as_double(0x3e5ade156a5dcb37LL), c10 = __longlong_as_double(0x3e928af3fca7ab0cLL),
+               c9 = __longlong_as_double(0x3ec71dee623fde64LL), c8 = __longlong_as_double(0x3efa01997c89e6b0LL),
+               c7 = __longlong_as_double(0x3f2a01a014761f6eLL), c6 = __longlong_as_double(0x3f56c16c1852b7b0LL),
+               c5 = __longlong_as_double(0x3f81111111122322LL), c4 = __longlong_as_double(0x3fa55555555502a1LL),
+               c3 = __longlong_as_double(0x3fc5555555555511LL), c2 = __longlong_as_double(0x3fe000000000000bLL);
+  const double n = __builtin_rint(x * kLog2e);
+  double r = __builtin_fma(kNegLn2Hi, n, x);
+  r = __builtin_fma(kNegLn2Lo, n, r);
+  double p;
+#define CCGP_FMA3(D, A, B, C) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(D) : "v"(A), "v"(B), "v"(C))
+  CCGP_FMA3(p, r, c11, c10);
+  CCGP_FMA3(p, r, p, c9);
+  CCGP_FMA3(p, r, p, c8);
+  CCGP_FMA3(p, r, p, c7);
+  CCGP_FMA3(p, r, p, c6);
+  CCGP_FMA3(p, r, p, c5);
+  CCGP_FMA3(p, r, p, c4);
+  CCGP_FMA3(p, r, p, c3);
+  CCGP_FMA3(p, r, p, c2);
+#undef CCGP_FMA3
+  p = __builtin_fma(r, p, 1.0);
+  p = __builtin_fma(r, p, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+#endif
+}
+
+// which exp the small-n evaluators (small_reg.hip, small.hip) use: 0 = polynomial, 1 = table (A/B: -DCCGP_SMALL_EXP_TABLE=1)
+#ifndef CCGP_SMALL_EXP_TABLE
+#define CCGP_SMALL_EXP_TABLE 0
+#endif
+__device__ __forceinline__ double exp_small(double dist, const double* tab) {
+#if CCGP_SMALL_EXP_TABLE
+  return exp_cov(dist, tab);
+#else
+  (void)tab;
+  return exp_cov_poly(dist);
 #endif
 }
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
   double* red = w2 + K;
   double* etab = red + 16;   // 2^(j/256) for exp_cov
 
-  exp_table_load(etab, tid, 256);
+  if (CCGP_SMALL_EXP_TABLE) exp_table_load(etab, tid, 256);
   for (int e = tid; e < K * d; e += 256) th[e] = a.params[b + (size_t)(K + e) * a.ldp];
   if (tid < K) {
     double w = a.params[b + (size_t)tid * a.ldp];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           double s = 0.0;
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + i] * th[c * d + k], xs[k * n + j], s);
           double dist = (us[c * n + i] + us[c * n + j]) + (-2.0 * s);
-          acc += w2[c] * exp_cov(dist, etab);
+          acc += w2[c] * exp_small(dist, etab);
         }
         v = post_scale * (acc / sw) + post_shift;
       } else if (i == n) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + j] * th[c * d + k], xt[k * a.mtile + t], s);
           // corr.vec order: (theta'x^2 - 2 X Theta x) + u_i   (HX:373)
           double dist = (ut[c * a.mtile + t] - 2.0 * s) + us[c * n + j];
-          acc += w2[c] * exp_cov(dist, etab);
+          acc += w2[c] * exp_small(dist, etab);
         }
         v = acc / sw;
       } else {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
   for (int k = 0; k < n; ++k) {
     __syncthreads();
     const double piv = A[k + (size_t)k * ld];
-    if (!(piv > pivot_tolerance(a.mode))) { bad = k + 1; break; }   // uniform: every thread reads the same word
+    if (!(piv > pivot_tolerance(a.mode, n))) { bad = k + 1; break; }   // uniform: every thread reads the same word
     const double rinv = 1.0 / piv;
     const double* colk = A + (size_t)k * ld;
     for (int j = k + 1 + wave; j < n; j += 4) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void small_kernel(SmallArgs a) {
           double s = 0.0;
           for (int k = 0; k < d; ++k) s = fma(xs[k * n + i] * th[c * d + k], xs[k * n + jt], s);
           double dist = (us[c * n + i] + us[c * n + jt]) + (-2.0 * s);
-          double rc = exp_cov(dist, etab);
+          double rc = exp_small(dist, etab);
           if (kk >= 0) { double df = xs[kk * n + i] - xs[kk * n + jt]; rc *= df * df; }
           acc = fma(Mit, rc, acc);
         }

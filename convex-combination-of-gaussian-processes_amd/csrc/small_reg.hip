@@ -51,10 +51,13 @@ struct RegArgs {
   double* logdet;      // optional output: sum_k log d_k
 };
 
-constexpr int kPerMat(int NP, int G, int NE = 1) {  // doubles of LDS per matrix
-  return kMaxK * NP /*us*/ + kMaxK * kMaxD /*th*/ + kMaxK /*w2*/ + 2 * (NP + G * NE) /*colbuf*/ + NP /*dvec*/ +
-         2 * NP /*zb*/ + 8 + (NE > 1 ? kMaxK * G * NE /*ut*/ + 3 * G * G * NE /*partial sums*/ : 0);
+// doubles of LDS per matrix, from the ACTUAL number of components and dimensions (round 3: sized for kMaxK / kMaxD
+// before -- 4 KB of th[] per matrix for a 2 x 4 table -- which left the prediction instances one workgroup per CU short)
+__host__ __device__ constexpr int kPerMat(int NP, int G, int NE, int K, int d) {
+  return K * NP /*us*/ + K * d /*th*/ + K /*w2*/ + 2 * (NP + G * NE) /*colbuf*/ + NP /*dvec*/ +
+         2 * NP /*zb*/ + 8 + (NE > 1 ? K * G * NE /*ut*/ + 3 * G * G * NE /*partial sums*/ : 0);
 }
+constexpr int kSmallExpTable = CCGP_SMALL_EXP_TABLE ? kExpTableDoubles : 0;
 
 template <int G>
 __device__ __forceinline__ void mat_sync() {
@@ -77,11 +80,11 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
   constexpr int NP = G * NB;       // padded order
-  constexpr int PM = kPerMat(NP, G, NE);
   constexpr int XR = G * NE;       // extra rows (y', 1', then test sites)
   constexpr int MT = XR - 2;       // test sites per chunk
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int n = a.n, d = a.d, K = a.K;
+  const int PM = kPerMat(NP, G, NE, K, d);
   const int tid = threadIdx.x, sub = tid / TPM, lt = tid % TPM;
   const int ty = lt % G, tx = lt / G;
   int b = a.draw0 + blockIdx.x * MPW + sub;
@@ -89,21 +92,21 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
   if (!valid) b = a.draw0 + a.B - 1;   // keep the wave alive (shared loads, barriers); results discarded
 
   double* etab = smem;                        // 2^(j/256) for exp_cov, shared by the workgroup
-  double* xs = etab + kExpTableDoubles;       // d x n, shared by the matrices of this workgroup
+  double* xs = etab + kSmallExpTable;         // d x n, shared by the matrices of this workgroup
   double* mine = xs + d * n + (size_t)sub * PM;
   double* us = mine;
-  double* th = us + kMaxK * NP;
-  double* w2 = th + kMaxK * kMaxD;
-  double* colbuf = w2 + kMaxK;                // [2][NP + XR]
+  double* th = us + K * NP;
+  double* w2 = th + K * d;
+  double* colbuf = w2 + K;                    // [2][NP + XR]
   double* dvec = colbuf + 2 * (NP + XR);
   double* zb = dvec + NP;                     // [2][NP]
   double* ut = zb + 2 * NP + 8;               // [K][XR]   (NE > 1)
-  double* psum = ut + kMaxK * XR;             // [3][XR][G] (NE > 1)
+  double* psum = ut + K * XR;                 // [3][XR][G] (NE > 1)
   const int t0 = blockIdx.y * MT;             // first test site of this chunk
   double* xt = xs + (size_t)d * n + (size_t)MPW * PM;     // [d][XR], shared by the workgroup (NE > 1)
 
   const int pb = a.shared_params ? 0 : b;
-  exp_table_load(etab, tid, 256);
+  if (CCGP_SMALL_EXP_TABLE) exp_table_load(etab, tid, 256);
   if (a.x_stride == 0) {
     for (int e = tid; e < n * d; e += 256) xs[e] = a.X[e];
   } else {
@@ -200,13 +203,13 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
             // every (r, c) is a matrix entry; entries above the diagonal of the diagonal blocks (aa == bb, ty < tx)
             // are computed too and zeroed below -- cheaper than a divergent branch
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
-            M[aa][bb] = fma(wq, exp_cov(dist, etab), M[aa][bb]);
+            M[aa][bb] = fma(wq, exp_small(dist, etab), M[aa][bb]);
             // pin the finished entry here: without the branch the compiler sinks the tail of every exp (ldexp + mix)
             // to the end of the component loop and keeps two temporaries per entry alive until then (580 B of scratch)
             asm volatile("" : "+v"(M[aa][bb]));
           } else if (r < n && c < n && r >= c) {
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
-            M[aa][bb] = fma(wq, exp_cov(dist, etab), M[aa][bb]);
+            M[aa][bb] = fma(wq, exp_small(dist, etab), M[aa][bb]);
           }
         }
       }
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
             double sd = 0.0;
             for (int k = 0; k < d; ++k) sd = fma(xs[k * n + c] * th[q * d + k], xt[k * XR + ridx], sd);
             const double dist = (ut[q * XR + ridx] - 2.0 * sd) + us[q * NP + c];
-            acc = fma(w2[q], exp_cov(dist, etab), acc);
+            acc = fma(w2[q], exp_small(dist, etab), acc);
           }
           v = acc / sw;
         }
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
   // ---- L' D L'^T on registers; one column broadcast through LDS per step ------------------------
   int bad = 0, cur = 0;
   // a bare log-determinant (entropy criteria, BSQ:856-877: the reference calls det(), nothing can "fail") keeps 0
-  const double ptol = a.logdet ? 0.0 : pivot_tolerance(a.mode);
+  const double ptol = a.logdet ? 0.0 : pivot_tolerance(a.mode, n);
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll 1
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
 template <int G, int NB, int NE>
 size_t reg_lds_bytes(const RegArgs& a) {
   constexpr int MPW = 256 / (G * G);
-  return sizeof(double) * (kExpTableDoubles + (size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G, NE) +
+  return sizeof(double) * (kSmallExpTable + (size_t)a.d * a.n + (size_t)MPW * kPerMat(G * NB, G, NE, a.K, a.d) +
                            (a.x_stride ? (size_t)MPW * a.d * a.n : 0) + (NE > 1 ? (size_t)a.d * G * NE : 0));
 }
 
@@ -431,13 +434,13 @@ void launch_one(hipStream_t s, const RegArgs& a) {
 
 constexpr int kPredictNE = 4;   // extra row-blocks of the prediction instances: 30 (G = 8) / 62 (G = 16) sites per chunk
 
-bool small_reg_supported(int n, int d, bool per_design, bool predict) {
+bool small_reg_supported(int n, int d, int K, bool per_design, bool predict) {
   if (n > 128) return false;
   const int G = n <= 64 ? 8 : 16;
   const int NB = (n + G - 1) / G;
   const int MPW = 256 / (G * G);
   const int NE = predict ? kPredictNE : 1;
-  return sizeof(double) * (kExpTableDoubles + (size_t)d * n + (size_t)MPW * kPerMat(G * NB, G, NE) +
+  return sizeof(double) * (kSmallExpTable + (size_t)d * n + (size_t)MPW * kPerMat(G * NB, G, NE, K, d) +
                            (per_design ? (size_t)MPW * d * n : 0) + (predict ? (size_t)d * G * NE : 0)) <=
          (size_t)kLdsBytes - 64;
 }

@@ -77,7 +77,7 @@ static void blas_restore(int prev) {
 }
 
 /* plain blocked Cholesky (lower, column-major), used only when no LAPACK could be bound.  ptol: a pivot <= ptol fails
- * (0 for the grid likelihood, DBL_EPSILON for the profile-beta likelihood whose reference path calls solve(R), which
+ * (0 for the grid likelihood, n * DBL_EPSILON for the profile-beta likelihood whose reference path calls solve(R), which
  * refuses rcond < eps, HX:454 -- the same rule as the device, csrc/ccgp_internal.h pivot_tolerance) */
 static int chol_builtin(double* A, int n, double ptol) {
   const int NB = 64;
@@ -201,7 +201,7 @@ int ccgp_cpu_loglik_batch(const double* X, int n, int d, const double* y, int K,
       const double* row = params + b;
       const double cs = sigma2 * sum_w2(row, K, ldp);
       build_cov(X, n, d, K, row, ldp, mode == 1 ? cs : 1.0, mode == 1 ? tau2 : 0.0, A, u, xt);
-      const int info = factor(A, n, mode == 0 ? 2.220446049250313e-16 : 0.0);
+      const int info = factor(A, n, mode == 0 ? n * 2.220446049250313e-16 : 0.0);
       if (info != 0) {
         if (status) status[b] = info;
         out_ll[b] = NAN;
@@ -258,7 +258,7 @@ int ccgp_cpu_predict_batch(const double* X, int n, int d, const double* y, int K
       const double* row = params + s;
       const double sw = sum_w2(row, K, ldp);
       build_cov(X, n, d, K, row, ldp, 1.0, 0.0, A, u, xt);
-      if (factor(A, n, 2.220446049250313e-16) != 0) {
+      if (factor(A, n, n * 2.220446049250313e-16) != 0) {
         for (int t = 0; t < m; ++t) mean[s + (size_t)t * S] = var[s + (size_t)t * S] = NAN;
         ++bad;
         continue;

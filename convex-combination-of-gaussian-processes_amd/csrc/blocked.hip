@@ -753,15 +753,12 @@ CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
 CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
 #undef CCGP_DEFINE_GEMM
 
-// Strip count for an update launch.  One workgroup per SIMD-set saturates a CU's four MFMA pipes, so the time of
-// a launch is a step function of its workgroup count in units of 256 (16.3 us per 128-deep block of K and per
-// step; the second resident workgroup of a CU only fills bubbles).  Round 1 cut tiles into column strips to fill
-// the last, partial step; with the diagonal tile as ONE long workgroup (it also factorises the block) half-width
-// strips no longer win anywhere (rocprofv3 per-launch tables, profiles/r02_update_schedule.md sections 3 and 6:
-// best-of per launch 25.57 ms against 25.70 ms at S = 1 for 64 matrices, and S = 1 ahead at every block column
-// for 512).  The S = 2 kernel remains for the rows-only sweeps of ccgp_predict_from_factorset (few, long rows)
-// and as a measurement switch.
-static int pick_strips(int /*nb8*/, int /*tiles*/) { return 1; }
+// Strip count of an update launch: always 1 since round 2.  One workgroup per SIMD-set saturates a CU's four MFMA
+// pipes, so the time of a launch is a step function of its workgroup count in units of 256 (16.3 us per 128-deep
+// block of K and per step; the second resident workgroup of a CU only fills bubbles); with the diagonal tile as ONE
+// long workgroup (it also factorises the block) whole launches of half-width strips no longer win anywhere
+// (profiles/r02_update_schedule.md sections 3 and 6).  The S = 2 kernel remains for the rows-only sweeps of
+// ccgp_predict_from_factorset (few, long rows) and as a measurement switch (CCGP_OPT_UPDATE_STRIPS).
 
 // Tiles of an update launch that should run as strips: the launch is W1 = nb8 (1 + tiles) workgroups at S = 1 and
 // takes ceil(W1 / 256) steps (one workgroup per CU saturates its MFMA pipes).  If the last step holds `rem` <= 128
@@ -1211,7 +1208,7 @@ struct GroupRun {
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;
     dg.ptol = g.ptol = pivot_tolerance(mean_mode, n);
-    force_s = h->opt_strips;   // ccgp_set_option(CCGP_OPT_UPDATE_STRIPS): 0 = pick_strips per launch
+    force_s = h->opt_strips;   // ccgp_set_option(CCGP_OPT_UPDATE_STRIPS): 0 = whole tiles (+ tail strips)
   }
 
   // T_ij = A_ij - sum_{k<j} L_ik L_jk' for every tile row of block column j (nothing to do at j = 0)
@@ -1220,7 +1217,7 @@ struct GroupRun {
     ScopedTimer t(h, CCGP_T_UPDATE, s);
     g.j = j;
     g.mode = 0;
-    launch_gemm(s, g, 0, force_s > 0 ? force_s : pick_strips(round_up(nb, 8), nt - 1 - j + w.ne));
+    launch_gemm(s, g, 0, force_s > 0 ? force_s : 1);
   }
 
   // L_jj, W_j = L_jj^-1, then L_ij = T_ij W_j' for the rows below

@@ -345,6 +345,56 @@ def ordinary_kriging_sigma2(handle, D_train, y_train, starts=8, rng=0):
     return Q / n, theta, beta
 
 
+def matern_MLEs(handle, D, y, nu, grid=96, lo=1e-3, hi=1e2):
+    """MLEs(D, y, nu) of the 1-D scripts (D1:455-471 = D1F:547-566): ordinary kriging with ONE Matern(nu) component;
+    theta minimises log.likeli = log det R(theta) + n log sigma2.MLE(theta) (D1:424-444), then beta.MLE and sigma2.MLE
+    at that theta (D1:467-468).  Combined.GP.fit feeds this sigma2 to the Combined-GP path (D1:994-995).
+
+    The reference starts nlminb at runif(1) and retries until solve() succeeds; the optimiser's path is not
+    reproducible (R's RNG), its optimum is.  Here the batched device likelihood (ccgp_loglik_batch, K = 1, Matern
+    family) evaluates a log-spaced grid of `grid` scale parameters (scaled by the design's range) in two calls, which
+    brackets the global minimum; a bounded scalar search refines it inside the bracket.
+    Returns dict(beta, sigma2, theta)."""
+    from scipy.optimize import minimize_scalar
+    from . import api
+    from .rsurface import _FamilyHandle
+
+    D = np.asarray(D, dtype=np.float64).reshape(-1, 1)
+    y = np.asarray(y, dtype=np.float64).ravel()
+    n = D.shape[0]
+    h = _FamilyHandle(handle, api.KERNEL_MATERN, float(nu))
+    span = max(float(D.max() - D.min()), 1e-12)
+
+    def parts(thetas):
+        """(Q, logdet, beta) per theta from two likelihood evaluations that differ in sigma2 only:
+        ll(s) = -(n log 2pi + n log s + logdet + Q / s) / 2."""
+        P = np.stack([np.ones_like(thetas), thetas], axis=1)
+        a, beta, st = h.loglik_batch(D, y, 1, P, 1.0)
+        b, _, _ = h.loglik_batch(D, y, 1, P, math.e)
+        Q = (n - 2.0 * (a - b)) / (1.0 - 1.0 / math.e)
+        logdet = -2.0 * a - n * math.log(2 * math.pi) - Q
+        bad = (st != 0) | ~np.isfinite(a) | ~(Q > 0)
+        return np.where(bad, np.nan, Q), np.where(bad, np.nan, logdet), beta
+
+    def objective(thetas):
+        Q, logdet, _ = parts(np.atleast_1d(np.asarray(thetas, dtype=np.float64)))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return logdet + n * np.log(Q / n)
+
+    th = span * np.exp(np.linspace(math.log(lo), math.log(hi), grid))
+    f = objective(th)
+    if not np.isfinite(f).any():
+        raise RuntimeError("matern_MLEs: the likelihood failed at every scale parameter of the search grid")
+    i = int(np.nanargmin(f))
+    a = th[max(i - 1, 0)]
+    b = th[min(i + 1, grid - 1)]
+    res = minimize_scalar(lambda t: float(np.nan_to_num(objective(math.exp(t))[0], nan=1e300)),
+                          bounds=(math.log(a), math.log(b)), method="bounded", options=dict(xatol=1e-10))
+    theta = math.exp(res.x) if res.fun <= f[i] else float(th[i])
+    Q, _, beta = parts(np.array([theta]))
+    return dict(beta=float(beta[0]), sigma2=float(Q[0] / n), theta=float(theta))
+
+
 def Combined_GP_fit(gp, D_train, y_train, D_new, start, N_max, samp_size, alpha_geweke, batch_size,
                     alpha=0.05, net_samp_size=None, y_new=None, sigma2=None, theta1_pars=None,
                     theta2_pars=None, rng=None, speculate=0):
@@ -352,11 +402,12 @@ def Combined_GP_fit(gp, D_train, y_train, D_new, start, N_max, samp_size, alpha_
     posterior draws (laplace + Metro) -> predictions with intervals at D.new."""
     rng = np.random.default_rng(rng)
     if sigma2 is None:
-        if getattr(gp, "script", "") in ("D1", "D1F"):
-            # the 1-D scripts take sigma2 from their own Matern MLEs() (D1:455-471, D1:994-995), a comparator model
-            # that is out of scope here; the Gaussian ordinary-kriging MLE below is what the OTHER scripts get from mlegp
-            raise ValueError("Combined_GP_fit: pass sigma2 for the 1-D scripts (they take it from MLEs(), D1:994-995)")
-        sigma2, _, _ = ordinary_kriging_sigma2(gp.h, D_train, y_train)
+        if getattr(gp, "script", "") in ("D1", "D1F") or hasattr(gp, "nu"):
+            # the 1-D scripts take sigma2 from their own Matern MLEs() (D1:455-471, D1:994-995)
+            base = getattr(gp.h, "_handle", gp.h)
+            sigma2 = matern_MLEs(base, D_train, y_train, gp.nu)["sigma2"]
+        else:
+            sigma2, _, _ = ordinary_kriging_sigma2(gp.h, D_train, y_train)
     net = net_samp_size or samp_size
     ff = factors_frame(gp, start, N_max, samp_size, batch_size, alpha_geweke, D_train, sigma2, y_train, net,
                        theta1_pars, theta2_pars, rng, speculate=speculate)

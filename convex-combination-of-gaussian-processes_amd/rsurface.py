@@ -181,6 +181,10 @@ class CombinedGP:
         mean, var = self.h.predict_from_factors(r.reshape(1, -1), beta, mf, v1, v2, R_Inv, sigma2)
         return np.array([[mean[0], var[0]]])
 
+    def cross_corr_matrix(self, D_old, D_new, theta):
+        """BSQ:835-848 cross.corr.matrix(D.old, D.new, theta): n.new x n.old, row t = corr.vec.ISO(D.new[t,], D.old, theta)."""
+        return self.h.corr_cross(np.atleast_2d(np.asarray(D_new, dtype=np.float64)), D_old, float(theta))
+
     # ------------------------------------------------------------------ entropy criteria (BSQ)
     def Entropy(self, D, p, theta1, theta2):
         """Batch Sequential ME Design.R:856-861: -det(Mixed.corr.matrix(D, p, theta1, theta2))."""

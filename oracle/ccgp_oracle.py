@@ -121,18 +121,19 @@ def sigma2_mle(R_inv, y, beta):
 
 
 # --------------------------------------------------------------------------- a12/a13
-def solve_inverse(R):
+def solve_inverse(R, tol=None):
     """base R solve(R) (HX:454) = solve.default(a, tol = .Machine$double.eps) -> La_solve: LAPACK dgesv(R, I), an error
     for an exactly singular U ("system is exactly singular"), THEN rcond = dgecon("1", LU, ||R||_1) and an error when
     rcond < tol ("system is computationally singular: reciprocal condition number = ...").  The reference wraps the
     call in try() and maps either error to R.Inv <- NA (HX:454-455).  Base R is not in the reference tree; restated
-    from its documented behaviour (?solve: "tol: the tolerance for detecting linear dependencies in the columns of a")."""
+    from its documented behaviour (?solve: "tol: the tolerance for detecting linear dependencies in the columns of a").
+    tol: the 1-D scripts pass tol = 1e-16 (D1:440)."""
     A = np.asarray(R, dtype=np.float64)
     x = np.linalg.inv(A)                      # dgesv(A, I); raises LinAlgError on an exactly singular U
     lu, _, info = sla.lapack.dgetrf(A)        # the same factorisation again, for the condition estimate
     anorm = np.abs(A).sum(axis=0).max()
     rcond, info = sla.lapack.dgecon(lu, anorm, norm="1")
-    if not rcond >= np.finfo(np.float64).eps:
+    if not rcond >= (np.finfo(np.float64).eps if tol is None else tol):
         raise np.linalg.LinAlgError("system is computationally singular: reciprocal condition number = %g" % rcond)
     return x
 
@@ -467,6 +468,17 @@ def corr_matrix_matern(nu, X, theta):
 def corr_vec_matern(x, X, theta, nu):
     """D1:383-389."""
     return matern_corr(nu, float(x) - np.asarray(X, dtype=np.float64).reshape(-1), theta)
+
+
+def log_likeli_1d(nu, theta, D, y):
+    """D1:437-444 log.likeli(nu, theta, D.train, y.train) = log(det(R)) + n log(sigma2.MLE): the ordinary-kriging
+    profile objective that MLEs() minimises with nlminb (D1:455-471); = D1F:527-537 with corr.matrix.Matern."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    R = corr_matrix_matern(nu, D, theta)
+    R_inv = solve_inverse(R, tol=1e-16)
+    beta = beta_mle(R_inv, y)
+    s2 = sigma2_mle(R_inv, y, beta)
+    return math.log(np.linalg.det(R)) + y.shape[0] * math.log(s2)
 
 
 def logpost_1d(D, theta_t, y, sigma2, nu):

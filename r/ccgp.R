@@ -124,6 +124,8 @@ ccgp.prediction.table <- function(D.test, draws, D.train, sigma2, y.train) {
 # Entropy criteria of the batch-sequential design script (Batch Sequential ME Design.R:856-877).
 # det() of the Schur complement = det(R(D.old U D.new)) / det(R(D.old)), so R.old.Inv is not needed.
 if (ccgp.script == "BSQ") {
+  cross.corr.matrix <- function(D.old, D.new, theta)                                      # BSQ:835-848: n.new x n.old
+    .Call("ccgp_R_corr_cross", .ccgp.mat(D.new), .ccgp.mat(D.old), as.double(rep(theta, ncol(D.new))))
   .ccgp.logdet <- function(D, p, theta1, theta2)
     .Call("ccgp_R_mixed_logdet_designs", matrix(as.double(D), ncol = 1), nrow(D), ncol(D), 2L,
           .ccgp.row(ncol(D), p, theta1, theta2))

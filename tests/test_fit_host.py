@@ -101,17 +101,3 @@ def test_results_table_has_the_reference_layout(tmp_path):
     np.testing.assert_array_equal(got[:, 9], table["y_hat"])
     assert np.isnan(got[:, 13:19]).all()
     np.testing.assert_array_equal(got[:, 19], table["y_true"])
-
-
-def test_one_dimensional_fit_needs_sigma2():
-    """The 1-D scripts take sigma2 from their own Matern MLEs() (D1:994-995), a comparator model that is out of
-    scope: Combined_GP_fit must say so instead of failing inside the device call (round-1 advisor finding)."""
-    import pytest
-    from ccgp_amd import fit
-
-    class Fake1D:
-        script = "D1"
-        h = None
-
-    with pytest.raises(ValueError, match="sigma2"):
-        fit.Combined_GP_fit(Fake1D(), np.zeros((8, 1)), np.zeros(8), np.zeros((3, 1)), [0, 0, 0], 10, 5, 0.5, 5)

@@ -4,6 +4,8 @@ reference records (Ground Vibrations Emulator/Results/Size 50 Results 1.txt: RMS
 import numpy as np
 import pytest
 
+from oracle import ccgp_oracle as orc
+
 from conftest import load_gv, load_qian
 
 pytestmark = pytest.mark.gpu
@@ -93,6 +95,47 @@ def test_one_dimensional_fit_matern(handle):
     t = gp.prediction_table(X, table["draws"][:5], X, float(np.var(y, ddof=1)), y)
     np.testing.assert_allclose(t["mean"], np.tile(y, (5, 1)), atol=1e-6)
     assert np.all(np.abs(t["var"]) < 1e-6)
+
+
+def test_matern_mles_is_the_minimum_of_the_1d_scripts_log_likeli(handle):
+    """MLEs(D, y, nu) (D1:455-471): theta minimises log.likeli = log det R + n log sigma2.MLE (D1:437-444); beta and
+    sigma2 are beta.MLE / sigma2.MLE at that theta.  Checked against the oracle's literal log.likeli: the device's
+    optimum is a local minimum of it, no point of a dense scan lies below it, and sigma2 / beta agree."""
+    from ccgp_amd import fit
+    from conftest import golden
+    g = golden("d1_golden.json")
+    X, y, nu = np.array(g["X"]), np.array(g["y"]), g["nu"]
+    m = fit.matern_MLEs(handle, X, y, nu)
+    f0 = orc.log_likeli_1d(nu, m["theta"], X.reshape(-1, 1), y)
+    scan = []
+    for t in np.exp(np.linspace(np.log(0.02), np.log(20.0), 200)):
+        try:
+            scan.append(orc.log_likeli_1d(nu, t, X.reshape(-1, 1), y))
+        except np.linalg.LinAlgError:            # solve(R, tol = 1e-16) refuses the matrix: the reference retries
+            pass
+    assert len(scan) > 50 and f0 <= min(scan) + 1e-8
+    for eps in (1e-3, -1e-3):
+        assert orc.log_likeli_1d(nu, m["theta"] * (1 + eps), X.reshape(-1, 1), y) >= f0 - 1e-9
+    R_inv = orc.solve_inverse(orc.corr_matrix_matern(nu, X.reshape(-1, 1), m["theta"]), tol=1e-16)
+    beta = orc.beta_mle(R_inv, y)
+    assert m["beta"] == pytest.approx(beta, rel=1e-7)
+    assert m["sigma2"] == pytest.approx(orc.sigma2_mle(R_inv, y, beta), rel=1e-7)
+
+
+def test_one_dimensional_fit_takes_sigma2_from_its_own_mles(handle):
+    """Combined.GP.fit of the 1-D script (D1:989-1001): no sigma2 argument -- it comes from MLEs()."""
+    from ccgp_amd import fit
+    from ccgp_amd.rsurface import CombinedGP1D
+    X = (np.arange(8) + np.array([0.3, 0.7, 0.5, 0.2, 0.8, 0.4, 0.6, 0.5])) / 8.0
+    f = lambda x: np.sin(10.0 * x)
+    D, y = X.reshape(-1, 1), f(X)
+    Dn = np.linspace(0.0, 1.0, 40).reshape(-1, 1)
+    gp = CombinedGP1D(5.0, handle=handle)
+    table = fit.Combined_GP_fit(gp, D, y, Dn, [0.0, 1.5, 0.0], 2000, 400, 0.5, 20, net_samp_size=200, y_new=f(Dn[:, 0]),
+                                rng=5, speculate=4)
+    assert table["sigma2"] == pytest.approx(fit.matern_MLEs(handle, D, y, 5.0)["sigma2"], rel=1e-12)
+    s = fit.comparison_summary(table)
+    assert s["rmspe"] < 0.35 * np.std(f(Dn[:, 0])) and s["coverage"] >= 0.8
 
 
 def test_anisotropic_2d_fit(handle):

@@ -611,6 +611,10 @@ def test_entropy_criteria_over_candidate_designs(handle):
     np.testing.assert_allclose(got, want, rtol=1e-9)
     assert gp.Entropy(designs[3], p, t1, t2) == pytest.approx(want[3], rel=1e-9)
     D_old, D_new = designs[0], -1.0 + 2.0 * rng.random((7, 2))
+    # cross.corr.matrix (BSQ:835-848), the override a script that calls it directly gets: n.new x n.old
+    C = gp.cross_corr_matrix(D_old, D_new, t2)
+    assert C.shape == (7, 14)
+    np.testing.assert_allclose(C, orc.cross_corr_matrix(D_old, D_new, t2), rtol=1e-12, atol=1e-300)
     got_aug = gp.Augmented_Mixed_Entropy(D_old, D_new, p, t1, t2)
     assert got_aug == pytest.approx(orc.augmented_mixed_entropy(D_old, D_new, p, t1, t2), rel=1e-8)
     # 21-point designs (14 + 7, the script's second stage) and a 9-D case on the G = 16 template

@@ -226,3 +226,17 @@ def test_solve_refuses_a_computationally_singular_matrix_like_base_r():
     # a well-conditioned matrix goes through and is the LAPACK inverse
     R = orc.mixed_corr_matrix_iso(D, 0.8, 0.3, 15.0)
     np.testing.assert_array_equal(orc.solve_inverse(R), np.linalg.inv(R))
+
+
+def test_log_likeli_of_the_1d_scripts_known_answer():
+    """D1:437-444: log(det(R)) + n log(sigma2.MLE), against a direct evaluation through eigenvalues / lstsq."""
+    g = golden("d1_golden.json")
+    X, y, nu = np.array(g["X"]).reshape(-1, 1), np.array(g["y"]), g["nu"]
+    R = orc.corr_matrix_matern(nu, X, 0.25)
+    w = np.linalg.eigvalsh(R)
+    one = np.ones(8)
+    a = np.linalg.solve(R, np.stack([y, one], axis=1))
+    beta = (one @ a[:, 0]) / (one @ a[:, 1])
+    r = y - beta
+    s2 = (r @ np.linalg.solve(R, r)) / 8
+    assert orc.log_likeli_1d(nu, 0.25, X, y) == pytest.approx(np.log(w).sum() + 8 * math.log(s2), rel=1e-9)

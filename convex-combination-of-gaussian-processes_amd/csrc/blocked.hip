@@ -1149,7 +1149,7 @@ __global__ void blocked_grad_reduce_kernel(GradReduceArgs g) {
 size_t blocked_ws_bytes(int npad, int nb, int ne) {
   const int nt = npad / kTile;
   size_t dbl = (size_t)nb * (npad + kTile * (1 + ne)) * npad + (size_t)nb * nt * kTile * kTile +
-               (size_t)nb * (nt + 2) + 64;
+               (size_t)nb * (nt + 2) + 64 + (size_t)npad * kMaxD + 16;
   return dbl * sizeof(double);
 }
 
@@ -1163,6 +1163,7 @@ BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
   w.invd = w.A + (size_t)nb * w.a_stride;
   w.z = w.invd + (size_t)nb * nt * kTile * kTile;  // logdet partials (nb x nt), then s11 and beta (nb each)
   w.fin = w.z + (size_t)nb * nt;
+  w.xpad = w.fin + (((size_t)2 * nb + 15) & ~(size_t)15);   // 128-byte aligned: whole s_load_dwordx16 lines
   return w;
 }
 
@@ -1193,7 +1194,7 @@ struct GroupRun {
     nt = npad / kTile;
     {
       ScopedTimer t(h, CCGP_T_COV, s);
-      launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld);
+      launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld, w.xpad);
       RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
       hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
       if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site

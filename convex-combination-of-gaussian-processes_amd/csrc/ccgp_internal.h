@@ -101,7 +101,7 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
 // the padding), z in [0, nb).  scale/shift: mode 0 -> (1, 0); mode 1 -> (sigma2*sum w^2, tau2).
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2, int ld);
+                      double tau2, int ld, double* xpad = nullptr);
 void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const double* X, int n, int d,
                               DrawView dv, int b0, int nb, double* Abase, size_t batch_stride, int ldo);
 
@@ -141,6 +141,7 @@ struct BlockedWs {
   double* invd;     // nb x nt x 128 x 128 inverses of the diagonal blocks
   double* z;        // nb x nt log-det partials
   double* fin;      // nb x 2: s11 = 1'R^-1 1 and beta per matrix (prediction pass)
+  double* xpad;     // npad x kMaxD: the design zero-padded to npad rows (scalar-load source of cov_kernel's columns)
   size_t a_stride;  // elements between consecutive matrices
   int ld;           // npad + 128 * (1 + ne)
   int ne;           // extra full tile rows (ceil(m / 128) for prediction, else 0)

@@ -36,11 +36,13 @@ struct CovArgs {
   int lower_tiles;  // 1: square, write only tiles with row-tile >= col-tile, pad identity to npad
   int npad;
   int raw_mix;      // 1: sum w_c^2 r_c without the division by sum w_c^2 (corr.vec.combined as written, D1F:470-480)
+  const double* colpad;   // SCOL instantiation: the design zero-padded to npad rows (npad x d, leading dimension npad)
 };
 
 // LDS: etab[256] | xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
 // FAM = 0: Gaussian (the hot instantiation: nothing of the Matern code in it); FAM = 1: Matern (D1:348-351)
-template <int FAM>
+// SCOL (lower-tile launches of the blocked path): the column coordinates come from scalar loads, see below
+template <int FAM, bool SCOL = false>
 __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int d = a.d, K = a.K;
@@ -116,14 +118,33 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   // per group, 3 x 16 dot products in registers: a third of the LDS reads): 179 VGPRs instead of 108, two
   // waves per SIMD instead of four, and 19.4 instead of 17.2 ms for 512 matrices -- the kernel lives on
   // occupancy (independent exp chains), not on LDS bandwidth.  Not kept.
+  // Round 3: the column coordinates x_jk are WAVE-UNIFORM (a wave owns 16 columns x 64 rows).  In the lower-tile
+  // launches of the blocked path they are read with scalar loads from a zero-padded copy of the design (two
+  // s_load_dwordx16 per dimension into SGPRs, K$-cached; the v_fma takes them as its one constant-bus operand)
+  // instead of 16 broadcast ds_reads per dimension and component: with three components the LDS pipe was as busy
+  // as the VALU (21 ds_read_b64 per entry against 57 fp64 instructions).
+  typedef double d8 __attribute__((ext_vector_type(8)));
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const double* __restrict__ bcol = SCOL ? a.colpad + j0 + wave_u * JW : nullptr;
   for (int c = 0; c < K; ++c) {
     double sdot[JW];
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) sdot[jj] = 0.0;
     for (int k = 0; k < d; ++k) {
       const double xr = xa[k * kCovRows + lane] * th[c * d + k];
+      if constexpr (SCOL) {
+        static_assert(JW == 16, "two 8-double scalar loads per dimension");
+        const d8 b0 = *reinterpret_cast<const d8*>(bcol + (size_t)k * a.npad);
+        const d8 b1 = *reinterpret_cast<const d8*>(bcol + (size_t)k * a.npad + 8);
 #pragma unroll
-      for (int jj = 0; jj < JW; ++jj) sdot[jj] = fma(xr, xb[k * kCovCols + jl0 + jj], sdot[jj]);
+        for (int jj = 0; jj < 8; ++jj) {
+          sdot[jj] = fma(xr, b0[jj], sdot[jj]);
+          sdot[8 + jj] = fma(xr, b1[jj], sdot[8 + jj]);
+        }
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) sdot[jj] = fma(xr, xb[k * kCovCols + jl0 + jj], sdot[jj]);
+      }
     }
     const double ur = ua[c * kCovRows + lane], wc = w2[c];
 #pragma unroll
@@ -153,6 +174,7 @@ void cov_prepare() {
   static unsigned long long attr_mask = 0;
   once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)cov_kernel<0>, "cov_kernel<0>");
+    raise_lds_limit((const void*)cov_kernel<0, true>, "cov_kernel<0, scalar columns>");
     raise_lds_limit((const void*)cov_kernel<1>, "cov_kernel<1>");
   });
 }
@@ -172,9 +194,19 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
   else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
 }
 
+namespace {
+// the design zero-padded to npad rows: xpad[i + k * npad]
+__global__ void pad_design_kernel(const double* X, int n, int d, int npad, double* xpad) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npad * d) return;
+  const int k = e / npad, i = e % npad;
+  xpad[e] = i < n ? X[i + (size_t)k * n] : 0.0;
+}
+}  // namespace
+
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2, int ld) {
+                      double tau2, int ld, double* xpad) {
   CovArgs a{};
   a.A = X; a.Bm = X; a.m = n; a.n = n; a.d = d;
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
@@ -183,8 +215,15 @@ void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv,
   cov_prepare();
   int nt64 = npad / 64;
   dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
-  if (dv.fam.id == 0) hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
-  else hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  if (dv.fam.id == 0 && xpad) {
+    hipLaunchKernelGGL(pad_design_kernel, dim3((npad * d + 255) / 256), dim3(256), 0, s, X, n, d, npad, xpad);
+    a.colpad = xpad;
+    hipLaunchKernelGGL((cov_kernel<0, true>), grid, dim3(256), cov_lds(d, dv.K), s, a);
+  } else if (dv.fam.id == 0) {
+    hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  } else {
+    hipLaunchKernelGGL(cov_kernel<1>, grid, dim3(256), cov_lds(d, dv.K), s, a);
+  }
 }
 
 // Batched cross-correlation rows for the blocked prediction path: for draw b0+z the m x n block

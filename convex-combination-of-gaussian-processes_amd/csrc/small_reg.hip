@@ -75,8 +75,24 @@ __device__ __forceinline__ void mat_sync() {
 // validity tests (r < n, c < n) and the index clamps disappear.  They compiled to one divergent branch per matrix
 // entry and component (s_and_saveexec / s_cbranch_execz / s_or + hazard s_nops around every exp): ~10 of the
 // ~45 instructions an entry costs in a kernel that is instruction-issue bound.
+// Waves per SIMD the register allocator is asked to fit (A/B switches; defaults = what measured fastest, profiles/r03/):
+// the kernel is bound by the latency of its per-column LDS round trip as much as by VALU issue, so for n <= 64 a
+// fourth wave per SIMD (128 VGPRs, at the price of 84 B of scratch per lane in the generation phase) is worth 8.6 %
+// on the Heat-Exchanger grid (9.15 -> 8.37 ms, same box); a fifth wave (102 VGPRs) spills the matrix itself: 17.2 ms.
+// G = 16 (64 < n <= 128): 4 stays (5: 6.18 -> 8.23 ms on the 2-D grid).  Prediction instances (NE = 4): 3 instead of 2
+// (Ground-Vibrations tables 4.52 -> 4.07 ms; 4: 4.83).
+#ifndef CCGP_SMALL_OCC_G8
+#define CCGP_SMALL_OCC_G8 4
+#endif
+#ifndef CCGP_SMALL_OCC_G16
+#define CCGP_SMALL_OCC_G16 4
+#endif
+#ifndef CCGP_SMALL_OCC_PRED
+#define CCGP_SMALL_OCC_PRED 3
+#endif
 template <int G, int NB, int NE, bool FULL = false>
-__global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_kernel(RegArgs a) {
+__global__ __launch_bounds__(256, NE > 1 ? CCGP_SMALL_OCC_PRED : (G == 8 ? CCGP_SMALL_OCC_G8 : CCGP_SMALL_OCC_G16))
+void small_reg_kernel(RegArgs a) {
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
   constexpr int NP = G * NB;       // padded order
@@ -265,7 +281,12 @@ __global__ __launch_bounds__(256, NE > 1 ? 2 : (G == 8 ? 3 : 4)) void small_reg_
         for (int e = 0; e < NE; ++e) cb[NP + ty + G * e] = E[e][kb];
       }
       mat_sync<G>();
-      const double piv = cb[k];
+      // every thread of the matrix reads the same word; handing it over through v_readfirstlane tells the compiler
+      // that it -- and with it `bad`, the loop exit and the buffer toggle -- is wave-uniform: scalar branch and
+      // scalar address arithmetic instead of exec-mask bookkeeping per column
+      const double piv_v = cb[k];
+      const double piv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(piv_v)),
+                                          __builtin_amdgcn_readfirstlane(__double2loint(piv_v)));
       if (!(piv > ptol)) { bad = k + 1; break; }   // uniform over the matrix's threads (pivot_tolerance: ccgp_internal.h)
       // 1 / pivot by v_rcp_f64 + two Newton steps (full precision, ~6 instructions instead of ~30)
       double rinv = __builtin_amdgcn_rcp(piv);

@@ -4,19 +4,23 @@
 busy fractions.  SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles (MI355X guide, PMC table)."""
 import collections, csv, json, sys
 tag = sys.argv[1]
+wl = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'      # cfg2 (n = 64: one wave per evaluation) | cfg3 (n = 100: one workgroup of 4 waves)
+waves_per_eval = 1 if wl == 'cfg2' else 4
 tot = collections.defaultdict(float)
 launches = 0
 for i in (1, 2, 3):
     seen = set()
-    for r in csv.DictReader(open('gpurun_out/%s/pmc_cfg2_%d/t_counter_collection.csv' % (tag, i))):
+    for r in csv.DictReader(open('gpurun_out/%s/pmc_%s_%d/t_counter_collection.csv' % (tag, wl, i))):
         if 'small_reg_kernel' not in r['Kernel_Name']:
             continue
         tot[r['Counter_Name']] += float(r['Counter_Value'])
         seen.add(r['Dispatch_Id'])
     launches = max(launches, len(seen))
-waves = tot['SQ_WAVES']
-out = {"source": "rocprofv3 --pmc (three passes) --kernel-trace -- python3 bench.py --workload cfg2 --steps 1 --warmup 1 --no-cpu-baseline; "
-                 "small_reg_kernel<8,8,1>, one wave per evaluation, 624 000 evaluations per launch",
+waves = tot['SQ_WAVES'] / waves_per_eval     # = evaluations
+out = {"source": "rocprofv3 --pmc (three passes) --kernel-trace -- python3 bench.py --workload %s --steps 1 --warmup 1 --no-cpu-baseline; " % wl +
+                 ("small_reg_kernel<8,8,1,full>, one wave per evaluation, 624 000 evaluations per launch" if wl == 'cfg2' else
+                  "small_reg_kernel<16,7,1>, one workgroup (4 waves) per evaluation, 103 680 evaluations per launch; per-evaluation "
+                  "figures are sums over the 4 waves"),
        "launches": launches, "raw": dict(tot)}
 if waves:
     per = lambda k: tot[k] / waves
@@ -31,5 +35,5 @@ if waves:
                                          "waiting_any": tot['SQ_WAIT_ANY'] / wc, "waiting_on_instruction": tot['SQ_WAIT_INST_ANY'] / wc,
                                          "waiting_on_lds": tot['SQ_WAIT_INST_LDS'] / wc}
     out["lds_bank_conflict_cycles_per_eval"] = per('SQ_LDS_BANK_CONFLICT')
-json.dump(out, open('profiles/%s/pmc_cfg2_summary.json' % tag, 'w'), indent=1)
+json.dump(out, open('profiles/%s/pmc_%s_summary.json' % (tag, wl), 'w'), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != 'raw'}, indent=1))

@@ -1321,7 +1321,8 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
 // only the forward substitution of its m cross-correlation rows: the SAME update / trsm tile kernels,
 // launched over the extra rows alone (rows_only), so the result is bit-identical to a full
 // ccgp_predict_batch sweep -- same kernels, same k order -- at O(m n^2) instead of O(n^3).
-void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int npad, int S, double* E,
+// Served in chunks of draws [s0, s0 + ns): the scratch rows E are sized under the handle's workspace limit.
+void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int npad, int S, int s0, int ns, double* E,
                                   size_t e_stride, int lde, int m, const int* status, double sigma2,
                                   double* mean, double* var) {
   static unsigned long long attr_mask = 0;
@@ -1333,10 +1334,12 @@ void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int
   const int nt = npad / kTile, ne = lde / kTile;
   hipStream_t s = h->stream;
   GemmArgs g{};
-  g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
-  g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = S; g.ld = w.ld; g.ne = ne;
+  g.invd_stride = (size_t)nt * kTile * kTile;
+  // draws [s0, s0 + ns) of the set's S: the factor arrays are offset, E holds this chunk's rows only
+  g.A = w.A + (size_t)s0 * w.a_stride; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd + (size_t)s0 * g.invd_stride;
+  g.nt = nt; g.nb = ns; g.ld = w.ld; g.ne = ne;
   g.extra_lower = 0; g.E = E; g.e_stride = e_stride; g.lde = lde; g.rows_only = 1;
-  const int nb8 = round_up(S, 8);
+  const int nb8 = round_up(ns, 8);
   for (int j = 0; j < nt; ++j) {
     g.j = j;
     if (j > 0) {
@@ -1352,9 +1355,9 @@ void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int
     }
   }
   ScopedTimer t(h, CCGP_T_SOLVE, s);
-  PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, m, E, e_stride, lde, w.fin, w.fin + S, status, 0, S,
+  PredFinishArgs pa{g.A, w.a_stride, npad, w.ld, n, m, E, e_stride, lde, w.fin + s0, w.fin + S + s0, status, s0, S,
                     sigma2, mean, var};
-  hipLaunchKernelGGL(predict_finish_kernel, dim3((m + 255) / 256, S), dim3(256), 0, s, pa);
+  hipLaunchKernelGGL(predict_finish_kernel, dim3((m + 255) / 256, ns), dim3(256), 0, s, pa);
 }
 
 }  // namespace ccgp

@@ -1191,17 +1191,36 @@ int ccgp_predict_from_factorset(ccgp_handle* h, const ccgp_factorset* fs, const 
   } else {
     const int ne = (m + kTile - 1) / kTile, lde = ne * kTile;
     const size_t e_stride = (size_t)lde * fs->npad;
-    rc = ensure_ws(h, sizeof(double) * e_stride * S);
+    // the m cross-correlation rows of every draw need lde x npad doubles of scratch: chunks of draws under the
+    // workspace limit and under what the device can give right now (the factor set itself holds most of it)
+    size_t limit = h->ws_limit, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t margin = size_t(256) << 20;
+      const size_t avail = free_b + h->ws_bytes > margin ? free_b + h->ws_bytes - margin : 0;
+      if (avail < limit) limit = avail;
+    }
+    size_t sc = limit / (sizeof(double) * e_stride);
+    if (sc < 1) sc = 1;
+    if (sc > (size_t)S) sc = S;
+    if (sc > 65535) sc = 65535;   // the draw index is a grid dimension
+    rc = ensure_ws(h, sizeof(double) * e_stride * sc);
+    while (rc == CCGP_ENOMEM && sc > 1) {
+      sc = (sc + 1) / 2;
+      rc = ensure_ws(h, sizeof(double) * e_stride * sc);
+    }
     if (rc) return rc;
     double* E = static_cast<double*>(h->ws);
-    CCGP_HIP(hipMemsetAsync(E, 0, sizeof(double) * e_stride * S, h->stream));
     DrawView dv{fs->params, S, fs->K, d};
     dv.fam = fs->fam;
-    {
-      ScopedTimer t(h, CCGP_T_COV);   // rows t = r(x_t)' (Mixed.corr.vec, HX:425-431)
-      launch_cov_cross_batched(h->stream, dXt, m, fs->X, n, d, dv, 0, S, E, e_stride, lde);
+    for (int s0 = 0; s0 < S; s0 += (int)sc) {
+      const int ns = std::min((int)sc, S - s0);
+      CCGP_HIP(hipMemsetAsync(E, 0, sizeof(double) * e_stride * ns, h->stream));
+      {
+        ScopedTimer t(h, CCGP_T_COV);   // rows t = r(x_t)' (Mixed.corr.vec, HX:425-431)
+        launch_cov_cross_batched(h->stream, dXt, m, fs->X, n, d, dv, s0, ns, E, e_stride, lde);
+      }
+      blocked_predict_from_factors(h, fs->w, n, fs->npad, S, s0, ns, E, e_stride, lde, m, fs->status, fs->sigma2, dmean, dvar);
     }
-    blocked_predict_from_factors(h, fs->w, n, fs->npad, S, E, e_stride, lde, m, fs->status, fs->sigma2, dmean, dvar);
     CCGP_LAUNCH_CHECK();
   }
   CCGP_HIP(hipMemcpyAsync(out_mean, dmean, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));

@@ -175,7 +175,7 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
 
 // forward-substitute the m cross-correlation rows held in E (S blocks of lde x npad, lde = 128 ceil(m / 128),
 // row t of block s = r(x_t)' for draw s) through the KEPT factors in w and finish mean / var (S x m)
-void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int npad, int S, double* E,
+void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int npad, int S, int s0, int ns, double* E,
                                   size_t e_stride, int lde, int m, const int* status, double sigma2,
                                   double* mean, double* var);
 

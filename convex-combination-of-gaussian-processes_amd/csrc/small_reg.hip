@@ -299,9 +299,15 @@ void small_reg_kernel(RegArgs a) {
       if (tx <= kk) lc[kb] = 0.0;   // columns <= k are finished
 #pragma unroll
       for (int aa = kb; aa < NB; ++aa) lr[aa] = cb[ty + G * aa];
-      // rows <= k of the diagonal block are NOT masked: lr[kb] only reaches M[kb][kb], and there a row r <= k
-      // meets either a finished column (protected by the lc mask above) or a column c > k >= r, i.e. an entry above
-      // the diagonal that nothing reads.  Three instructions per column less in an issue-bound kernel.
+      // FULL instantiation (n = G NB, the Heat-Exchanger grid): rows <= k of the diagonal block are NOT masked: lr[kb]
+      // only reaches M[kb][kb], and there a row r <= k meets either a finished column (protected by the lc mask
+      // above) or a column c > k >= r, i.e. an entry above the diagonal that nothing reads.  Three instructions per
+      // column less in an issue-bound kernel.  The general instantiation keeps the mask (round-2 advisor): the
+      // unnormalised above-diagonal entries could reach Inf on a nearly singular matrix, and Inf * 0 = NaN would
+      // then leak into finished entries with status still 0.
+      if constexpr (!FULL) {
+        if (ty <= kk) lr[kb] = 0.0;   // rows <= k are finished
+      }
       double le[NE];
 #pragma unroll
       for (int e = 0; e < NE; ++e) le[e] = cb[NP + ty + G * e];

@@ -51,6 +51,16 @@ def test_n520_blocked_path_two_test_sets(handle):
         # interleaving other work on the handle does not disturb the kept factors
         handle.loglik_batch(X, y, 2, P[:2], 2.0)
         np.testing.assert_array_equal(fs.predict(sets[0])[0], handle.predict_batch(X, y, 2, P, sets[0], 1.0)[0])
+        # a workspace limit that holds the scratch rows of two draws only (200 sites -> 256 x 640 doubles per draw):
+        # the sweep over the kept factors runs in chunks of draws (round-2 advisor) -- same bits, any chunking
+        whole = fs.predict(sets[1])
+        handle.set_workspace_limit(2 * 256 * 640 * 8 + 4096)
+        try:
+            chunked = fs.predict(sets[1])
+        finally:
+            handle.set_workspace_limit(200 << 30)
+        np.testing.assert_array_equal(chunked[0], whole[0])
+        np.testing.assert_array_equal(chunked[1], whole[1])
     # oracle for one draw and a few sites
     w, Th = orc.unpack_params(P[0], 2, 3)
     R = orc.mixed_corr_matrix_general(X, w, Th)

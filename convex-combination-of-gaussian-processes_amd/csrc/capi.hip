@@ -661,13 +661,23 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
     const int npad = round_up(n, kTile), nt = npad / kTile, ne = nt, ntiles = nt * (nt + 1) / 2;
     const size_t per_extra = sizeof(double) * ((size_t)ntiles * P + npad);
     size_t per = blocked_ws_bytes(npad, 1, ne) + per_extra;
-    int nbc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, h->ws_limit / per));
+    size_t glimit = h->ws_limit, gfree = 0, gtotal = 0;
+    if (hipMemGetInfo(&gfree, &gtotal) == hipSuccess) {
+      const size_t margin = size_t(1) << 30;
+      const size_t avail = gfree + h->ws_bytes > margin ? gfree + h->ws_bytes - margin : 0;
+      if (avail < glimit) glimit = avail;
+    }
+    int nbc = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)B, 65535), glimit / per));
     size_t need_st = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
                      2 * Carver::al(sizeof(double) * (size_t)B * P) + 2 * Carver::al(sizeof(double) * B) +
                      Carver::al(sizeof(int) * (size_t)B);
     int rc = ensure_stage(h, need_st);
     if (rc) return rc;
     rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, ne) + (size_t)nbc * per_extra + 512);
+    while (rc == CCGP_ENOMEM && nbc > 1) {   // as in loglik_dev: halve the chunk until the workspace fits
+      nbc = (nbc + 1) / 2;
+      rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, ne) + (size_t)nbc * per_extra + 512);
+    }
     if (rc) return rc;
     Carver c(h->stage);
     double* dX = c.take<double>((size_t)n * d);
@@ -997,9 +1007,13 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   if (dv.fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
     // blocked path: the m cross-correlation rows ride along as extra tile rows of the sweep
     const int npad = round_up(n, kTile), ne = (m + kTile - 1) / kTile;
-    const int nbc = blocked_chunk(h, npad, S, ne);
+    int nbc = blocked_chunk(h, npad, S, ne);
     size_t extra = Carver::al(sizeof(double) * (size_t)S) * 2 + Carver::al(sizeof(int) * (size_t)S);
     int rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, ne) + extra);
+    while (rc == CCGP_ENOMEM && nbc > 1) {   // another handle / process took the memory in between: smaller chunks
+      nbc = (nbc + 1) / 2;
+      rc = ensure_ws(h, blocked_ws_bytes(npad, nbc, ne) + extra);
+    }
     if (rc) return rc;
     // scratch for outputs the caller did not ask for lives behind the matrices
     Carver tail(static_cast<char*>(h->ws) + blocked_ws_bytes(npad, nbc, ne));

@@ -243,6 +243,19 @@ def cpu_predict_sample(sets, P5, draws_per_core=8):
             "sample": "%d draws x 17 sets on %d cores in %.2f s; %d draws of set 1 on one core in %.2f s" % (S, cores, t_all, s1, t_one)}
 
 
+def cpu_logpost_latency(X, y, sigma2, calls=200):
+    """The oracle's logpost (the reference's operation sequence in numpy: solve(R) + beta.MLE + dmnorm) on the Qian
+    set, one call at a time: an emulation of what one R-level logpost costs, not a measurement of R."""
+    from oracle import ccgp_oracle as orc
+    theta_t = [math.log(0.3), math.log(15.0), math.log(4.0)]
+    orc.logpost(X, theta_t, y, sigma2, "HX", (7, 3, 3, 28))
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        orc.logpost(X, theta_t, y, sigma2, "HX", (7, 3, 3, 28))
+    el = (time.perf_counter() - t0) / calls
+    return {"us_per_call": 1e6 * el, "unit": "us per oracle.logpost call (numpy, reference operation sequence)", "calls": calls}
+
+
 def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2):
     big = X.shape[0] > 1000
     c = cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core=2 if big else 2000, one_core_evals=2 if big else 4000)
@@ -436,6 +449,7 @@ def run_loglik_workload(c):
             X3, y3, P3, K3, s23 = sec_in["cfg3"]
             cpu_sec["cfg3"] = cpu_compiled_loglik(X3, y3, P3, K3, s23, api.MEAN_ZERO_PLUS_TAU2, 1e4, 800, 2000)
             cpu_sec["cfg5"] = cpu_predict_sample(*sec_in["cfg5"])
+            cpu_sec["logpost"] = cpu_logpost_latency(X2, y2, s22)
             if args.n == 4096:
                 cpu_sec["cfg4_predict"] = cpu_predict_n4096(X, y, K, P[:CFG4_PREDICT_DRAWS], sigma2)
 
@@ -664,6 +678,23 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
                                  "ms_per_pass": 1e3 * e2e5, "predictions_per_s": pairs / e2e5, "over_kernel": e2e5 / el5}})
     for entry, key in zip(items, ("cfg2", "cfg3", "cfg5")):
         entry["cpu"] = cpu_sec.get(key)
+    # the SEQUENTIAL caller: Metro evaluates one proposal per logpost call (HX:512) and keeps R.Inv (HX:520) -- latency,
+    # not throughput.  Host-pointer ccgp_logpost on the Qian set, with and without the n x n inverse coming back.
+    theta_t = np.array([math.log(0.3), math.log(15.0), math.log(4.0)])
+    pars = np.array([7.0, 3.0, 3.0, 28.0])
+    calls = 200
+    lat = {}
+    for want in (True, False):
+        h.logpost(X2, y2, s22, api.PRIOR_INVGAMMA, theta_t, pars, want_Rinv=want)
+        t1 = time.perf_counter()
+        for _ in range(calls):
+            h.logpost(X2, y2, s22, api.PRIOR_INVGAMMA, theta_t, pars, want_Rinv=want)
+        lat[want] = (time.perf_counter() - t1) / calls
+    items.append({"workload": "logpost latency: Qian n=64, ONE draw per call through the host-pointer ccgp_logpost (what Metro "
+                              "calls once per proposal, HX:505-512)",
+                  "value": 1.0 / lat[True], "unit": "logpost calls/s (sequential, with R.Inv)",
+                  "us_per_call_with_Rinv": 1e6 * lat[True], "us_per_call_value_only": 1e6 * lat[False], "calls": calls,
+                  "cpu": cpu_sec.get("logpost")})
     # prediction at a second test set from factors kept in HBM, against re-factorising
     if args.workload == "cfg4" and X.shape[0] == 4096:
         Sf, mf_ = CFG4_PREDICT_DRAWS, CFG4_PREDICT_SITES

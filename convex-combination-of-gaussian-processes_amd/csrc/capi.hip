@@ -83,6 +83,24 @@ int ensure_stage(ccgp_handle* h, size_t bytes) {
   return CCGP_OK;
 }
 
+// pinned host buffer of the latency path (ccgp_logpost): grow-only
+int ensure_pin(ccgp_handle* h, size_t bytes) {
+  if (bytes <= h->pin_bytes) return CCGP_OK;
+  if (h->pin) {
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+    (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_bytes = 0;
+  }
+  const size_t want = bytes + bytes / 4 + 4096;
+  if (hipHostMalloc(&h->pin, want, hipHostMallocDefault) != hipSuccess) {
+    h->pin = nullptr;
+    return fail(h, CCGP_ENOMEM, "pinned host buffer of " + std::to_string(want) + " B failed");
+  }
+  h->pin_bytes = want;
+  return CCGP_OK;
+}
+
 // bump allocator over the staging buffer (256-byte aligned pieces)
 struct Carver {
   char* base;
@@ -350,6 +368,7 @@ int ccgp_destroy(ccgp_handle* h) {
   }
   if (h->ws) (void)hipFree(h->ws);
   if (h->stage) (void)hipFree(h->stage);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return CCGP_OK;
@@ -794,12 +813,54 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   // so the likelihood, beta and R^-1 come out of the same elimination
   double ll = 0.0, beta = 0.0;
   int st = 0;
-  if (!out_Rinv) {
+  CCGP_HIP(hipSetDevice(h->device));
+  const bool gauss = h->fam.id == 0;
+  const bool reg_val = gauss && small_reg_supported(n, d, K) && !h->opt_small_lds;
+  const bool reg_inv = gauss && small_reg_inverse_supported(n, d, K) && !h->opt_small_lds;
+  if (out_Rinv ? reg_inv : reg_val) {
+    // The sequential caller's path (Metro evaluates ONE proposal per logpost call, HX:505-512): latency, not
+    // throughput.  Inputs are packed into a pinned host buffer and cross PCIe in ONE copy, the results (log-lik,
+    // beta, status[, R^-1]) come back in one: 300 -> ~100 us per call with R.Inv at n = 64, 113 -> ~60 us without.
+    const size_t in_d = (size_t)n * d + n + P;                       // X | y | row
+    const size_t out_d = 3 + (out_Rinv ? (size_t)n * n : 0);         // ll, beta, status (as one double slot) | R^-1
+    int rc2 = ensure_pin(h, sizeof(double) * (in_d + out_d));
+    if (rc2) return rc2;
+    rc2 = ensure_stage(h, Carver::al(sizeof(double) * in_d) + Carver::al(sizeof(double) * out_d) + 256);
+    if (rc2) return rc2;
+    double* pin = static_cast<double*>(h->pin);
+    std::memcpy(pin, X, sizeof(double) * (size_t)n * d);
+    std::memcpy(pin + (size_t)n * d, y, sizeof(double) * n);
+    std::memcpy(pin + (size_t)n * d + n, row.data(), sizeof(double) * P);
+    Carver c(h->stage);
+    double* din = c.take<double>(in_d);
+    double* dout = c.take<double>(out_d);
+    double* dX = din;
+    double* dy = din + (size_t)n * d;
+    double* dp = dy + n;
+    int* dst = reinterpret_cast<int*>(dout + 2);
+    CCGP_HIP(hipMemcpyAsync(din, pin, sizeof(double) * in_d, hipMemcpyHostToDevice, h->stream));
+    DrawView dv{dp, 1, K, d};
+    dv.fam = h->fam;
+    {
+      ScopedTimer t(h, CCGP_T_FUSED);
+      if (out_Rinv)
+        launch_small_reg_inverse(h->stream, dX, n, d, dy, dv, 0, sigma2, dout + 3, dout, dout + 1, dst);
+      else
+        launch_small_reg_loglik(h->stream, dX, n, d, dy, dv, 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, dout, dout + 1, dst);
+    }
+    CCGP_LAUNCH_CHECK();
+    double* pout = pin + in_d;
+    CCGP_HIP(hipMemcpyAsync(pout, dout, sizeof(double) * out_d, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+    ll = pout[0];
+    beta = pout[1];
+    std::memcpy(&st, pout + 2, sizeof(int));
+    if (out_Rinv) std::memcpy(out_Rinv, pout + 3, sizeof(double) * (size_t)n * n);
+  } else if (!out_Rinv) {
     int rc = ccgp_loglik_batch(h, X, n, d, y, K, row.data(), 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, &ll, &beta,
                                &st);
     if (rc < 0) return rc;
   } else {
-    CCGP_HIP(hipSetDevice(h->device));
     const bool blocked = h->fam.id != 0 || n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64;
     const int npad = round_up(n, kTile), nt = npad / kTile;
     size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +

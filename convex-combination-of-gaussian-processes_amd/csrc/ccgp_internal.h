@@ -72,6 +72,9 @@ struct ccgp_handle {
   // small staging buffers for the host-pointer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
+  // pinned host buffer: inputs and results of the one-draw-per-call path (ccgp_logpost) cross PCIe in one copy each
+  void* pin = nullptr;
+  size_t pin_bytes = 0;
   std::string err;
   ccgp::KernelFamily fam;
   unsigned timing = 0;   // bit i set: launch groups with id i are bracketed by HIP events
@@ -131,6 +134,11 @@ void launch_small_reg_predict(hipStream_t s, const double* X, int n, int d, cons
                               double* beta, int* status);
 void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int d, DrawView dv, int B,
                                      double* logdet, int* status);
+// solve(R) of ONE draw (logpost with R.Inv, HX:454) on the register-resident scheme; likelihood and beta of the same
+// factorisation come with it
+bool small_reg_inverse_supported(int n, int d, int K);
+void launch_small_reg_inverse(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int draw,
+                              double sigma2, double* Rinv, double* loglik, double* beta, int* status);
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                              int B, double sigma2, int mean_mode, double tau2, double* loglik,
                              double* beta, int* status);

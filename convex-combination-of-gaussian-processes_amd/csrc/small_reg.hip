@@ -13,6 +13,10 @@
 //           matrices per workgroup -- n <= 64 (Heat-Exchanger grid, n = 64)
 //   G = 16: one workgroup per matrix, one barrier per column -- 64 < n <= 128
 // NB = ceil(n / G) is a template parameter so that every register index is static.
+// INV (round 3, G = 16, NE = NB + 1): the extra rows are the IDENTITY -- solve(R) of logpost (HX:454), one matrix per
+// call: Metro's sequential caller.  After the sweep row t holds z_t = L'^-1 e_t; Z goes to LDS and
+// R^-1 = Z' D^-1 Z is formed by all 256 threads (the in-LDS kernel of small.hip back-substituted one row per
+// thread: 208 us per call at n = 64 against ~50 here).
 // NE = number of G-row blocks of EXTRA rows: NE = 1 is the plain likelihood (rows y', 1');
 // NE = 4 serves prediction (predict.post, HX:655-673): rows 2.. of the extra block are the
 // cross-correlations r(x_t)' of a chunk of G NE - 2 test sites, eliminated like every other row,
@@ -49,13 +53,15 @@ struct RegArgs {
   size_t x_stride;     // 0: one shared design
   int shared_params;   // 1: params is a single row
   double* logdet;      // optional output: sum_k log d_k
+  double* Rinv;        // INV instantiation: n x n explicit inverse of the (normalised) mixed correlation matrix
 };
 
 // doubles of LDS per matrix, from the ACTUAL number of components and dimensions (round 3: sized for kMaxK / kMaxD
 // before -- 4 KB of th[] per matrix for a 2 x 4 table -- which left the prediction instances one workgroup per CU short)
-__host__ __device__ constexpr int kPerMat(int NP, int G, int NE, int K, int d) {
+__host__ __device__ constexpr int kPerMat(int NP, int G, int NE, int K, int d, bool inv = false) {
   return K * NP /*us*/ + K * d /*th*/ + K /*w2*/ + 2 * (NP + G * NE) /*colbuf*/ + NP /*dvec*/ +
-         2 * NP /*zb*/ + 8 + (NE > 1 ? K * G * NE /*ut*/ + 3 * G * G * NE /*partial sums*/ : 0);
+         2 * NP /*zb*/ + 8 +
+         (inv ? NP * (NP + 1) /*Z, row stride NP + 1*/ : (NE > 1 ? K * G * NE /*ut*/ + 3 * G * G * NE /*partial sums*/ : 0));
 }
 constexpr int kSmallExpTable = CCGP_SMALL_EXP_TABLE ? kExpTableDoubles : 0;
 
@@ -90,9 +96,10 @@ __device__ __forceinline__ void mat_sync() {
 #ifndef CCGP_SMALL_OCC_PRED
 #define CCGP_SMALL_OCC_PRED 3
 #endif
-template <int G, int NB, int NE, bool FULL = false>
-__global__ __launch_bounds__(256, NE > 1 ? CCGP_SMALL_OCC_PRED : (G == 8 ? CCGP_SMALL_OCC_G8 : CCGP_SMALL_OCC_G16))
+template <int G, int NB, int NE, bool FULL = false, bool INV = false>
+__global__ __launch_bounds__(256, INV ? 1 : (NE > 1 ? CCGP_SMALL_OCC_PRED : (G == 8 ? CCGP_SMALL_OCC_G8 : CCGP_SMALL_OCC_G16)))
 void small_reg_kernel(RegArgs a) {
+  static_assert(!INV || (G == 16 && NE == NB + 1 && !FULL), "the inverse runs one matrix per workgroup with n identity rows");
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
   constexpr int NP = G * NB;       // padded order
@@ -100,7 +107,7 @@ void small_reg_kernel(RegArgs a) {
   constexpr int MT = XR - 2;       // test sites per chunk
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int n = a.n, d = a.d, K = a.K;
-  const int PM = kPerMat(NP, G, NE, K, d);
+  const int PM = kPerMat(NP, G, NE, K, d, INV);
   const int tid = threadIdx.x, sub = tid / TPM, lt = tid % TPM;
   const int ty = lt % G, tx = lt / G;
   int b = a.draw0 + blockIdx.x * MPW + sub;
@@ -116,8 +123,9 @@ void small_reg_kernel(RegArgs a) {
   double* colbuf = w2 + K;                    // [2][NP + XR]
   double* dvec = colbuf + 2 * (NP + XR);
   double* zb = dvec + NP;                     // [2][NP]
-  double* ut = zb + 2 * NP + 8;               // [K][XR]   (NE > 1)
-  double* psum = ut + K * XR;                 // [3][XR][G] (NE > 1)
+  double* ut = zb + 2 * NP + 8;               // [K][XR]   (NE > 1, prediction)
+  double* psum = ut + K * XR;                 // [3][XR][G] (NE > 1, prediction)
+  double* zmat = zb + 2 * NP + 8;             // [NP][NP + 1] (INV): row t = L'^-1 e_t
   const int t0 = blockIdx.y * MT;             // first test site of this chunk
   double* xt = xs + (size_t)d * n + (size_t)MPW * PM;     // [d][XR], shared by the workgroup (NE > 1)
 
@@ -135,7 +143,7 @@ void small_reg_kernel(RegArgs a) {
     const double w = a.params[pb + (size_t)lt * a.ldp];
     w2[lt] = w * w;
   }
-  if constexpr (NE > 1) {
+  if constexpr (NE > 1 && !INV) {
     for (int e = tid; e < d * XR; e += 256) {
       const int k = e / XR, r = e % XR, t = t0 + r - 2;
       xt[e] = (r >= 2 && t < a.m) ? a.Xt[t + (size_t)k * a.m] : 0.0;
@@ -148,7 +156,7 @@ void small_reg_kernel(RegArgs a) {
     for (int k = 0; k < d; ++k) { const double v = xs[k * n + i]; s += v * v * th[c * d + k]; }
     us[c * NP + i] = s;
   }
-  if constexpr (NE > 1) {
+  if constexpr (NE > 1 && !INV) {
     for (int e = lt; e < K * XR; e += TPM) {
       const int c = e / XR, r = e % XR;
       double sq = 0.0;
@@ -247,6 +255,7 @@ void small_reg_kernel(RegArgs a) {
       if (FULL || c < n) {
         if (ridx == 0) v = a.y[c];
         else if (ridx == 1) v = 1.0;
+        else if (INV) v = (ridx - 2 == c) ? 1.0 : 0.0;   // identity rows: row 2 + t = e_t'
         else if (NE > 1 && t0 + ridx - 2 < a.m) {
           // Mixed.corr.vec (HX:425-431), corr.vec operation order (HX:373): (theta'x^2 - 2 X Theta x) + u_i
           double acc = 0.0;
@@ -373,6 +382,35 @@ void small_reg_kernel(RegArgs a) {
       if (a.logdet) a.logdet[b] = bad ? kNaN : logdet;
     }
   }
+  if constexpr (INV) {
+    // R^-1 = Z' D^-1 Z with Z[t][c] = (L'^-1)[c][t] (zero for c < t): Z to LDS (row stride NP + 1: the threads of a
+    // wave read consecutive rows), 1 / d_c in place of d_c, then every thread forms its share of the lower triangle
+    constexpr int ZS = NP + 1;
+    const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+    mat_sync<G>();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int t = ty + G * e - 2;
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) {
+        const int c = tx + G * bb;
+        if (t >= 0 && t < n && c < n) zmat[t * ZS + c] = E[e][bb];
+      }
+    }
+    for (int c = lt; c < n; c += TPM) dvec[c] = bad ? 0.0 : 1.0 / dvec[c];
+    mat_sync<G>();
+    if (valid)
+      for (int idx = lt; idx < n * n; idx += TPM) {
+        const int i = idx % n, j = idx / n;
+        if (i < j) continue;
+        double acc = 0.0;
+        for (int c = i; c < n; ++c) acc = fma(zmat[i * ZS + c] * dvec[c], zmat[j * ZS + c], acc);
+        if (bad) acc = kNaN;
+        a.Rinv[i + (size_t)j * n] = acc;
+        a.Rinv[j + (size_t)i * n] = acc;
+      }
+    return;
+  }
   if constexpr (NE > 1) {
     // mean = beta + (z_y - beta z_1).w ,  var = sigma2 (1 - w.w + (1 - z_1.w)^2 / (z_1.z_1)),
     // dot products weighted by 1/d_k; w' = extra row of the test site (predict.post, HX:667-670)
@@ -461,6 +499,46 @@ void launch_one(hipStream_t s, const RegArgs& a) {
 
 constexpr int kPredictNE = 4;   // extra row-blocks of the prediction instances: 30 (G = 8) / 62 (G = 16) sites per chunk
 
+// ---- explicit inverse of ONE draw's matrix (solve(R), HX:454) on the register-resident scheme ------------------
+template <int NB>
+static size_t inv_lds_bytes(int n, int d, int K) {
+  return sizeof(double) * (kSmallExpTable + (size_t)d * n + (size_t)kPerMat(16 * NB, 16, NB + 1, K, d, true));
+}
+
+bool small_reg_inverse_supported(int n, int d, int K) {
+  if (n > 128) return false;
+  const int NB = (n + 15) / 16;
+  return sizeof(double) * (kSmallExpTable + (size_t)d * n + (size_t)kPerMat(16 * NB, 16, NB + 1, K, d, true)) <=
+         (size_t)kLdsBytes - 64;
+}
+
+template <int NB>
+static void launch_inv(hipStream_t s, const RegArgs& a) {
+  static unsigned long long attr_mask = 0;
+  once_per_device(attr_mask, [] {
+    raise_lds_limit((const void*)small_reg_kernel<16, NB, NB + 1, false, true>, "small_reg_kernel<inverse>");
+  });
+  hipLaunchKernelGGL((small_reg_kernel<16, NB, NB + 1, false, true>), dim3(1, 1), dim3(256), inv_lds_bytes<NB>(a.n, a.d, a.K), s, a);
+}
+
+void launch_small_reg_inverse(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int draw,
+                              double sigma2, double* Rinv, double* loglik, double* beta, int* status) {
+  RegArgs a{};
+  a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
+  a.draw0 = draw; a.B = 1; a.sigma2 = sigma2; a.mode = 0; a.tau2 = 0.0;
+  a.loglik = loglik; a.beta = beta; a.status = status; a.Rinv = Rinv; a.m = 0; a.S = 1;
+  switch ((n + 15) / 16) {
+    case 1: launch_inv<1>(s, a); break;
+    case 2: launch_inv<2>(s, a); break;
+    case 3: launch_inv<3>(s, a); break;
+    case 4: launch_inv<4>(s, a); break;
+    case 5: launch_inv<5>(s, a); break;
+    case 6: launch_inv<6>(s, a); break;
+    case 7: launch_inv<7>(s, a); break;
+    default: launch_inv<8>(s, a); break;
+  }
+}
+
 bool small_reg_supported(int n, int d, int K, bool per_design, bool predict) {
   if (n > 128) return false;
   const int G = n <= 64 ? 8 : 16;
@@ -512,7 +590,11 @@ void launch_small_reg_predict(hipStream_t s, const double* X, int n, int d, cons
 template <int NE>
 static void dispatch(hipStream_t s, const RegArgs& a) {
   const int n = a.n;
-  if (n <= 64) {
+  // A handful of evaluations (Metro's one proposal per logpost call, a speculative batch of a few candidates) is a
+  // LATENCY problem: one wave per matrix leaves the chip empty and runs the whole elimination on 64 lanes; the
+  // 16 x 16 grid puts four waves on each matrix (n = 64, one evaluation: 41 -> 25 us of kernel time).
+  const bool wide = NE == 1 && a.x_stride == 0 && a.B <= 64;
+  if (n <= 64 && !wide) {
     switch ((n + 7) / 8) {
       case 1: launch_one<8, 1, NE>(s, a); break;
       case 2: launch_one<8, 2, NE>(s, a); break;
@@ -525,6 +607,10 @@ static void dispatch(hipStream_t s, const RegArgs& a) {
     }
   } else {
     switch ((n + 15) / 16) {
+      case 1: if constexpr (NE == 1) { launch_one<16, 1, NE>(s, a); break; }
+      case 2: if constexpr (NE == 1) { launch_one<16, 2, NE>(s, a); break; }
+      case 3: if constexpr (NE == 1) { launch_one<16, 3, NE>(s, a); break; }
+      case 4: if constexpr (NE == 1) { launch_one<16, 4, NE>(s, a); break; }
       case 5: launch_one<16, 5, NE>(s, a); break;
       case 6: launch_one<16, 6, NE>(s, a); break;
       case 7: launch_one<16, 7, NE>(s, a); break;

@@ -80,6 +80,26 @@ def test_device_exp_is_within_two_ulp_down_to_underflow(handle):
     assert np.isnan(rn[5]) and np.isfinite(np.delete(rn, 5)).all()
 
 
+def test_small_n_evaluation_does_not_depend_on_the_batch_it_travels_in(handle):
+    """Batches of <= 64 evaluations run on the 16 x 16 thread grid (four waves per matrix: latency), larger ones at
+    n <= 64 on the 8 x 8 grid (one wave per matrix: throughput).  Every matrix entry sees the same rank-1 updates in
+    the same order either way, so an evaluation's bits must not depend on which one it got."""
+    D, y, _, _ = load_qian()
+    rng = np.random.default_rng(21)
+    P = np.array([orc.params_from_iso(rng.uniform(0.5, 0.95), rng.uniform(0.2, 1.0), rng.uniform(5, 30), 4) for _ in range(150)])
+    for mode, tau2 in ((0, 0.0), (1, 2500.0)):
+        big = handle.loglik_batch(D, y, 2, P, 37.0, mode, tau2)
+        for lo, hi in ((0, 1), (7, 8), (100, 140)):
+            small = handle.loglik_batch(D, y, 2, P[lo:hi], 37.0, mode, tau2)
+            np.testing.assert_array_equal(small[0], big[0][lo:hi])
+            np.testing.assert_array_equal(small[1], big[1][lo:hi])
+    # a 50-point design (n < 64, not a multiple of 8 or 16)
+    Dg, yg, _, _ = load_gv(50)
+    Pg = np.array([orc.params_from_iso(0.7, 0.3 + 0.01 * i, 15.0, 9) for i in range(90)])
+    big = handle.loglik_batch(Dg, yg, 2, Pg, 10.0)
+    np.testing.assert_array_equal(handle.loglik_batch(Dg, yg, 2, Pg[40:43], 10.0)[0], big[0][40:43])
+
+
 def test_corr_kernels_aniso(handle):
     from ccgp_amd.rsurface import CombinedGP
     gp = CombinedGP("ANI", handle=handle)

@@ -636,28 +636,51 @@ int ccgp_loglik_batch(ccgp_handle* h, const double* X, int n, int d, const doubl
   if (B == 0) return CCGP_OK;
   CCGP_HIP(hipSetDevice(h->device));
   const int P = K + K * d;
-  size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * n) +
-                Carver::al(sizeof(double) * (size_t)B * P) + 2 * Carver::al(sizeof(double) * B) +
-                Carver::al(sizeof(int) * (size_t)B);
-  int rc = ensure_stage(h, need);
+  // inputs X | y | params and results loglik | beta | status, each contiguous on the device
+  const size_t in_d = (size_t)n * d + n + (size_t)B * P;
+  const size_t out_d = 2 * (size_t)B + ((size_t)B + 1) / 2;
+  int rc = ensure_stage(h, Carver::al(sizeof(double) * in_d) + Carver::al(sizeof(double) * out_d));
   if (rc) return rc;
   Carver c(h->stage);
-  double* dX = c.take<double>((size_t)n * d);
-  double* dy = c.take<double>(n);
-  double* dp = c.take<double>((size_t)B * P);
-  double* dll = c.take<double>(B);
-  double* dbeta = c.take<double>(B);
-  int* dst = c.take<int>(B);
-  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
+  double* din = c.take<double>(in_d);
+  double* dout = c.take<double>(out_d);
+  double* dX = din;
+  double* dy = din + (size_t)n * d;
+  double* dp = dy + n;
+  double* dll = dout;
+  double* dbeta = dout + B;
+  int* dst = reinterpret_cast<int*>(dout + 2 * (size_t)B);
+  // A small call (a speculative batch of Metropolis candidates, the points of a numerical derivative) is dominated by
+  // the host side: through pageable memory every one of the three uploads and three downloads is a staged,
+  // synchronous copy of its own.  Up to 1 MiB the payload goes through the handle's pinned buffer: ONE copy each way.
+  const bool pinned = sizeof(double) * (in_d + out_d) <= (size_t(1) << 20) && ensure_pin(h, sizeof(double) * (in_d + out_d)) == CCGP_OK;
+  if (pinned) {
+    double* pin = static_cast<double*>(h->pin);
+    std::memcpy(pin, X, sizeof(double) * (size_t)n * d);
+    std::memcpy(pin + (size_t)n * d, y, sizeof(double) * n);
+    std::memcpy(pin + (size_t)n * d + n, params, sizeof(double) * (size_t)B * P);
+    CCGP_HIP(hipMemcpyAsync(din, pin, sizeof(double) * in_d, hipMemcpyHostToDevice, h->stream));
+  } else {
+    CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
+  }
   rc = loglik_dev(h, dX, n, d, dy, K, dp, B, sigma2, mean_mode, tau2, dll, dbeta, dst);
   if (rc) return rc;
   std::vector<int> st(B);
-  CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
-  if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (pinned) {
+    double* pout = static_cast<double*>(h->pin) + in_d;
+    CCGP_HIP(hipMemcpyAsync(pout, dout, sizeof(double) * out_d, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+    std::memcpy(out_loglik, pout, sizeof(double) * B);
+    if (out_beta) std::memcpy(out_beta, pout + B, sizeof(double) * B);
+    std::memcpy(st.data(), pout + 2 * (size_t)B, sizeof(int) * (size_t)B);
+  } else {
+    CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+    if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+  }
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
   return count_bad(st.data(), B);
 }

@@ -30,3 +30,10 @@ for n in (100, 300):
         for _ in range(20):
             h.logpost(Xn, yn, 1.0, 2, theta_t, None, want_Rinv=want)
         print(n, 'Rinv' if want else 'value', 'us/call %.1f' % (1e6 * (time.perf_counter() - t0) / 20))
+# a speculative Metropolis batch: 7 candidates per ccgp_loglik_batch call (host pointers)
+P7 = np.array([np.concatenate([[0.8, 0.2], np.full(4, 0.3 + 0.01 * i), np.full(4, 15.0)]) for i in range(7)])
+h.loglik_batch(X, y, 2, P7, s2)
+t0 = time.perf_counter()
+for _ in range(200):
+    h.loglik_batch(X, y, 2, P7, s2)
+print('loglik_batch, 7 draws per call: us/call %.1f' % (1e6 * (time.perf_counter() - t0) / 200))

@@ -840,15 +840,13 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   const bool gauss = h->fam.id == 0;
   const bool reg_val = gauss && small_reg_supported(n, d, K) && !h->opt_small_lds;
   const bool reg_inv = gauss && small_reg_inverse_supported(n, d, K) && !h->opt_small_lds;
-  if (out_Rinv ? reg_inv : reg_val) {
+  const size_t in_d = (size_t)n * d + n + P;                       // X | y | row
+  const size_t out_d = 3 + (out_Rinv ? (size_t)n * n : 0);         // ll, beta, status (as one double slot) | R^-1
+  if ((out_Rinv ? reg_inv : reg_val) && ensure_pin(h, sizeof(double) * (in_d + out_d)) == CCGP_OK) {
     // The sequential caller's path (Metro evaluates ONE proposal per logpost call, HX:505-512): latency, not
     // throughput.  Inputs are packed into a pinned host buffer and cross PCIe in ONE copy, the results (log-lik,
     // beta, status[, R^-1]) come back in one: 300 -> ~100 us per call with R.Inv at n = 64, 113 -> ~60 us without.
-    const size_t in_d = (size_t)n * d + n + P;                       // X | y | row
-    const size_t out_d = 3 + (out_Rinv ? (size_t)n * n : 0);         // ll, beta, status (as one double slot) | R^-1
-    int rc2 = ensure_pin(h, sizeof(double) * (in_d + out_d));
-    if (rc2) return rc2;
-    rc2 = ensure_stage(h, Carver::al(sizeof(double) * in_d) + Carver::al(sizeof(double) * out_d) + 256);
+    int rc2 = ensure_stage(h, Carver::al(sizeof(double) * in_d) + Carver::al(sizeof(double) * out_d) + 256);
     if (rc2) return rc2;
     double* pin = static_cast<double*>(h->pin);
     std::memcpy(pin, X, sizeof(double) * (size_t)n * d);

@@ -272,6 +272,8 @@ __device__ __forceinline__ double exp_cov(double dist, const double* tab) {
 // register-resident small-n evaluators, where the table variant measured no faster (round 3, profiles/r03/): their
 // waves already wait on LDS (column broadcasts of the elimination) and 65 data-dependent table reads per thread add
 // bank conflicts to that queue.
+// SC: Horner constants as scalar (SGPR) operands instead of VGPRs -- see below
+template <bool SC = false>
 __device__ __forceinline__ double exp_cov_poly(double dist) {
   const double x = -dist;
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -289,16 +291,35 @@ __device__ __forceinline__ double exp_cov_poly(double dist) {
   double r = __builtin_fma(kNegLn2Hi, n, x);
   r = __builtin_fma(kNegLn2Lo, n, r);
   double p;
+  // Horner constants: "v" operands hold 20 VGPRs, which at four waves per SIMD the compiler re-materialises with ~1.7
+  // v_mov_b64 per exp; as "s" operands (a VOP3 instruction takes one scalar operand) they cost SGPRs only.  Which is
+  // faster depends on what the register allocator makes of the rest of the kernel (same-box A/B, profiles/r03):
+  // scalar constants gain 2 % in the general n = 100 kernel (6.23 -> 6.10 ms) and lose 10 % in the n = 64 FULL
+  // instantiation (8.38 -> 9.20 ms: 148 instead of 84 B of scratch), so the caller chooses.
+  if constexpr (SC) {
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "s"(c11), "v"(c10));
+#define CCGP_FMA3(D, A, B, C) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(D) : "v"(A), "v"(B), "s"(C))
+    CCGP_FMA3(p, r, p, c9);
+    CCGP_FMA3(p, r, p, c8);
+    CCGP_FMA3(p, r, p, c7);
+    CCGP_FMA3(p, r, p, c6);
+    CCGP_FMA3(p, r, p, c5);
+    CCGP_FMA3(p, r, p, c4);
+    CCGP_FMA3(p, r, p, c3);
+    CCGP_FMA3(p, r, p, c2);
+#undef CCGP_FMA3
+  } else {
 #define CCGP_FMA3(D, A, B, C) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(D) : "v"(A), "v"(B), "v"(C))
-  CCGP_FMA3(p, r, c11, c10);
-  CCGP_FMA3(p, r, p, c9);
-  CCGP_FMA3(p, r, p, c8);
-  CCGP_FMA3(p, r, p, c7);
-  CCGP_FMA3(p, r, p, c6);
-  CCGP_FMA3(p, r, p, c5);
-  CCGP_FMA3(p, r, p, c4);
-  CCGP_FMA3(p, r, p, c3);
-  CCGP_FMA3(p, r, p, c2);
+    CCGP_FMA3(p, r, c11, c10);
+    CCGP_FMA3(p, r, p, c9);
+    CCGP_FMA3(p, r, p, c8);
+    CCGP_FMA3(p, r, p, c7);
+    CCGP_FMA3(p, r, p, c6);
+    CCGP_FMA3(p, r, p, c5);
+    CCGP_FMA3(p, r, p, c4);
+    CCGP_FMA3(p, r, p, c3);
+    CCGP_FMA3(p, r, p, c2);
+  }
 #undef CCGP_FMA3
   p = __builtin_fma(r, p, 1.0);
   p = __builtin_fma(r, p, 1.0);
@@ -310,12 +331,13 @@ __device__ __forceinline__ double exp_cov_poly(double dist) {
 #ifndef CCGP_SMALL_EXP_TABLE
 #define CCGP_SMALL_EXP_TABLE 0
 #endif
+template <bool SC = false>
 __device__ __forceinline__ double exp_small(double dist, const double* tab) {
 #if CCGP_SMALL_EXP_TABLE
   return exp_cov(dist, tab);
 #else
   (void)tab;
-  return exp_cov_poly(dist);
+  return exp_cov_poly<SC>(dist);
 #endif
 }
 

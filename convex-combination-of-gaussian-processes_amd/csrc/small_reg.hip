@@ -227,13 +227,13 @@ void small_reg_kernel(RegArgs a) {
             // every (r, c) is a matrix entry; entries above the diagonal of the diagonal blocks (aa == bb, ty < tx)
             // are computed too and zeroed below -- cheaper than a divergent branch
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
-            M[aa][bb] = fma(wq, exp_small(dist, etab), M[aa][bb]);
+            M[aa][bb] = fma(wq, exp_small<!FULL>(dist, etab), M[aa][bb]);
             // pin the finished entry here: without the branch the compiler sinks the tail of every exp (ldexp + mix)
             // to the end of the component loop and keeps two temporaries per entry alive until then (580 B of scratch)
             asm volatile("" : "+v"(M[aa][bb]));
           } else if (r < n && c < n && r >= c) {
             const double dist = (us[q * NP + r] + us[q * NP + c]) + (-2.0 * sdot[aa][j]);
-            M[aa][bb] = fma(wq, exp_small(dist, etab), M[aa][bb]);
+            M[aa][bb] = fma(wq, exp_small<!FULL>(dist, etab), M[aa][bb]);
           }
         }
       }
@@ -263,7 +263,7 @@ void small_reg_kernel(RegArgs a) {
             double sd = 0.0;
             for (int k = 0; k < d; ++k) sd = fma(xs[k * n + c] * th[q * d + k], xt[k * XR + ridx], sd);
             const double dist = (ut[q * XR + ridx] - 2.0 * sd) + us[q * NP + c];
-            acc = fma(w2[q], exp_small(dist, etab), acc);
+            acc = fma(w2[q], exp_small<!FULL>(dist, etab), acc);
           }
           v = acc / sw;
         }

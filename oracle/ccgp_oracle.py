@@ -1,7 +1,12 @@
 """numpy/scipy restatement of the reference's per-draw GP evaluation.
 
-TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  PARITY UNPINNED (no R, no
-reference golden vectors); cross-checked by oracle/mp_check.py at 50 digits.
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  What pins it: the reference holds no tests and no
+golden vectors, but it holds ONE recorded output, `Ground Vibrations Emulator/Results/Size 50 Results 1.txt`; its
+single-GP columns are reproduced by corr_matrix / corr_vec / solve / beta_mle / the predictive formulas to 1e-8 on all
+450 numbers (tests/test_reference_pins.py), the hyperprior pair hard-coded at HX:774-775 is the argmax of
+choose_hyperpars, and the Combined-GP columns agree up to Monte-Carlo noise.  PARITY UNPINNED for what no reference-held
+number covers: the log-likelihood scalar itself (arbitrated by oracle/mp_check.py at 50 digits and by LAPACK), the Halton
+start index, every Matern / spline / ADV result, and base R's solve() tolerance rule (restated from its documentation).
 
 Every function names the reference lines it follows.  Abbreviations:
   HX  = Heat Exchanger Emulator/Combined GP Heat Exchanger.R

@@ -289,9 +289,9 @@ __global__ void row_logmeanexp_kernel(const double* logs, int N, int take_log, d
 // ---- hyperprior grid: the G x N table of draws, built on the device (likeli.hyperpars HX:554-559) ----------
 // qtab[s * N + j] = qgamma(1 - u_j, shape_s, rate 1),  u_j = runif.halton(N, 1)[j]
 __global__ void grid_qtab_kernel(const double* shapes, int ns, int N, double* qtab) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ns * N) return;
-  const int s = idx / N, j = idx % N;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)ns * N) return;
+  const int s = (int)(idx / N), j = (int)(idx % N);
   qtab[idx] = qgamma_unit(1.0 - halton2((unsigned)j + 1u), shapes[s]);
 }
 

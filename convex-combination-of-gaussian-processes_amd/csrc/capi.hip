@@ -780,7 +780,10 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   if (int frc = check_family(h, dv.fam, d, K)) return frc;
   {
     ScopedTimer t(h, CCGP_T_FUSED);
-    launch_small_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst, dgp);
+    if (small_reg_inverse_supported(n, d, K) && !h->opt_small_lds)
+      launch_small_reg_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst);
+    else
+      launch_small_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst, dgp);
   }
   CCGP_LAUNCH_CHECK();
   std::vector<int> st(B);

@@ -139,6 +139,8 @@ void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int
 bool small_reg_inverse_supported(int n, int d, int K);
 void launch_small_reg_inverse(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int draw,
                               double sigma2, double* Rinv, double* loglik, double* beta, int* status);
+void launch_small_reg_grad(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int B,
+                           double sigma2, double* loglik, double* beta, double* grad, int* status);
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                              int B, double sigma2, int mean_mode, double tau2, double* loglik,
                              double* beta, int* status);

@@ -53,7 +53,9 @@ struct RegArgs {
   size_t x_stride;     // 0: one shared design
   int shared_params;   // 1: params is a single row
   double* logdet;      // optional output: sum_k log d_k
-  double* Rinv;        // INV instantiation: n x n explicit inverse of the (normalised) mixed correlation matrix
+  double* Rinv;        // INV = 1: n x n explicit inverse of the (normalised) mixed correlation matrix
+  double* grad;        // INV = 2: d loglik / d params, Btot x P column-major (element (b, j) at grad[b + j * Btot])
+  int Btot;
 };
 
 // doubles of LDS per matrix, from the ACTUAL number of components and dimensions (round 3: sized for kMaxK / kMaxD
@@ -96,10 +98,11 @@ __device__ __forceinline__ void mat_sync() {
 #ifndef CCGP_SMALL_OCC_PRED
 #define CCGP_SMALL_OCC_PRED 3
 #endif
-template <int G, int NB, int NE, bool FULL = false, bool INV = false>
+// INV: 0 = none, 1 = explicit inverse (solve(R), HX:454), 2 = analytic gradient of the profile-beta log-likelihood
+template <int G, int NB, int NE, bool FULL = false, int INV = 0>
 __global__ __launch_bounds__(256, INV ? 1 : (NE > 1 ? CCGP_SMALL_OCC_PRED : (G == 8 ? CCGP_SMALL_OCC_G8 : CCGP_SMALL_OCC_G16)))
 void small_reg_kernel(RegArgs a) {
-  static_assert(!INV || (G == 16 && NE == NB + 1 && !FULL), "the inverse runs one matrix per workgroup with n identity rows");
+  static_assert(!INV || (G == 16 && NE == NB + 1 && !FULL), "the inverse / gradient runs one matrix per workgroup with n identity rows");
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
   constexpr int NP = G * NB;       // padded order
@@ -107,7 +110,7 @@ void small_reg_kernel(RegArgs a) {
   constexpr int MT = XR - 2;       // test sites per chunk
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int n = a.n, d = a.d, K = a.K;
-  const int PM = kPerMat(NP, G, NE, K, d, INV);
+  const int PM = kPerMat(NP, G, NE, K, d, INV != 0);
   const int tid = threadIdx.x, sub = tid / TPM, lt = tid % TPM;
   const int ty = lt % G, tx = lt / G;
   int b = a.draw0 + blockIdx.x * MPW + sub;
@@ -399,16 +402,86 @@ void small_reg_kernel(RegArgs a) {
     }
     for (int c = lt; c < n; c += TPM) dvec[c] = bad ? 0.0 : 1.0 / dvec[c];
     mat_sync<G>();
-    if (valid)
-      for (int idx = lt; idx < n * n; idx += TPM) {
-        const int i = idx % n, j = idx / n;
-        if (i < j) continue;
-        double acc = 0.0;
-        for (int c = i; c < n; ++c) acc = fma(zmat[i * ZS + c] * dvec[c], zmat[j * ZS + c], acc);
-        if (bad) acc = kNaN;
-        a.Rinv[i + (size_t)j * n] = acc;
-        a.Rinv[j + (size_t)i * n] = acc;
+    if constexpr (INV == 1) {
+      if (valid)
+        for (int idx = lt; idx < n * n; idx += TPM) {
+          const int i = idx % n, j = idx / n;
+          if (i < j) continue;
+          double acc = 0.0;
+          for (int c = i; c < n; ++c) acc = fma(zmat[i * ZS + c] * dvec[c], zmat[j * ZS + c], acc);
+          if (bad) acc = kNaN;
+          a.Rinv[i + (size_t)j * n] = acc;
+          a.Rinv[j + (size_t)i * n] = acc;
+        }
+    } else {
+      // ---- gradient (build-defined extension; the reference differentiates numerically, HX:493) ------------------
+      //   M = (alpha alpha' - Sigma^-1) / 2,  Sigma = cs R,  cs = sigma2 sum w^2,  alpha = Sigma^-1 (y - beta 1)
+      //   d loglik / d w_q      =  2 sigma2 w_q   sum_ab M_ab R_q,ab
+      //   d loglik / d theta_qk = -  sigma2 w_q^2 sum_ab M_ab (x_ak - x_bk)^2 R_q,ab
+      // (the profile-beta term drops out: d loglik / d beta = 0 at beta_hat).  R^-1 entries come from Z as in the
+      // inverse; R_q is regenerated from X; every thread takes pairs (a >= b), off-diagonal pairs count twice.
+      constexpr int kGD = 16;                                  // dimensions per accumulator group
+      double* alpha = colbuf;                                  // [NP]   (the column buffers are free now)
+      double* part = colbuf + NP;                              // [4][1 + kGD] wave partial sums
+      const double beta = zb[2 * NP];
+      for (int i = lt; i < n; i += TPM) {
+        double s = 0.0;
+        for (int c = i; c < n; ++c) s = fma(zmat[i * ZS + c] * dvec[c], zb[c] - beta * zb[NP + c], s);
+        alpha[i] = s / cs;
       }
+      mat_sync<G>();
+      const int P = K + K * d;
+      const int lane64 = lt & 63, wv = lt >> 6;
+      for (int q = 0; q < K; ++q) {
+        const double wq = a.params[pb + (size_t)q * a.ldp];
+        for (int k0 = 0; k0 < d; k0 += kGD) {
+          double gs = 0.0, hk[kGD];
+#pragma unroll
+          for (int k = 0; k < kGD; ++k) hk[k] = 0.0;
+          if (!bad)
+            for (int idx = lt; idx < n * n; idx += TPM) {
+              const int i = idx % n, j = idx / n;
+              if (i < j) continue;
+              double rinv = 0.0;
+              for (int c = i; c < n; ++c) rinv = fma(zmat[i * ZS + c] * dvec[c], zmat[j * ZS + c], rinv);
+              const double m = (i == j ? 0.5 : 1.0) * (alpha[i] * alpha[j] - rinv / cs);
+              double sd = 0.0;
+              for (int k = 0; k < d; ++k) sd = fma(xs[k * n + i] * th[q * d + k], xs[k * n + j], sd);
+              const double dist = (us[q * NP + i] + us[q * NP + j]) + (-2.0 * sd);
+              const double v = m * exp_small<true>(dist, etab);
+              gs += v;
+#pragma unroll
+              for (int k = 0; k < kGD; ++k)
+                if (k0 + k < d) {
+                  const double df = xs[(k0 + k) * n + i] - xs[(k0 + k) * n + j];
+                  hk[k] = fma(v, df * df, hk[k]);
+                }
+            }
+          for (int off = 32; off > 0; off >>= 1) {
+            gs += __shfl_xor(gs, off, 64);
+#pragma unroll
+            for (int k = 0; k < kGD; ++k)
+              if (k0 + k < d) hk[k] += __shfl_xor(hk[k], off, 64);
+          }
+          if (lane64 == 0) {
+            part[wv * (1 + kGD)] = gs;
+#pragma unroll
+            for (int k = 0; k < kGD; ++k) part[wv * (1 + kGD) + 1 + k] = hk[k];
+          }
+          mat_sync<G>();
+          if (lt < 1 + kGD && valid) {
+            const double tot = (part[lt] + part[(1 + kGD) + lt]) + (part[2 * (1 + kGD) + lt] + part[3 * (1 + kGD) + lt]);
+            if (lt == 0) {
+              if (k0 == 0) a.grad[b + (size_t)q * a.Btot] = bad ? kNaN : 2.0 * a.sigma2 * wq * tot;
+            } else if (k0 + lt - 1 < d) {
+              a.grad[b + (size_t)(K + q * d + k0 + lt - 1) * a.Btot] = bad ? kNaN : -a.sigma2 * wq * wq * tot;
+            }
+          }
+          mat_sync<G>();
+        }
+      }
+      (void)P;
+    }
     return;
   }
   if constexpr (NE > 1) {
@@ -512,13 +585,33 @@ bool small_reg_inverse_supported(int n, int d, int K) {
          (size_t)kLdsBytes - 64;
 }
 
-template <int NB>
+template <int NB, int INV>
 static void launch_inv(hipStream_t s, const RegArgs& a) {
   static unsigned long long attr_mask = 0;
   once_per_device(attr_mask, [] {
-    raise_lds_limit((const void*)small_reg_kernel<16, NB, NB + 1, false, true>, "small_reg_kernel<inverse>");
+    raise_lds_limit((const void*)small_reg_kernel<16, NB, NB + 1, false, INV>, INV == 1 ? "small_reg_kernel<inverse>" : "small_reg_kernel<gradient>");
   });
-  hipLaunchKernelGGL((small_reg_kernel<16, NB, NB + 1, false, true>), dim3(1, 1), dim3(256), inv_lds_bytes<NB>(a.n, a.d, a.K), s, a);
+  const int kMaxGrid = 1 << 20;
+  RegArgs c = a;
+  for (int b0 = 0; b0 < a.B; b0 += kMaxGrid) {
+    c.draw0 = a.draw0 + b0;
+    c.B = a.B - b0 < kMaxGrid ? a.B - b0 : kMaxGrid;
+    hipLaunchKernelGGL((small_reg_kernel<16, NB, NB + 1, false, INV>), dim3(c.B, 1), dim3(256), inv_lds_bytes<NB>(a.n, a.d, a.K), s, c);
+  }
+}
+
+template <int INV>
+static void dispatch_inv(hipStream_t s, const RegArgs& a) {
+  switch ((a.n + 15) / 16) {
+    case 1: launch_inv<1, INV>(s, a); break;
+    case 2: launch_inv<2, INV>(s, a); break;
+    case 3: launch_inv<3, INV>(s, a); break;
+    case 4: launch_inv<4, INV>(s, a); break;
+    case 5: launch_inv<5, INV>(s, a); break;
+    case 6: launch_inv<6, INV>(s, a); break;
+    case 7: launch_inv<7, INV>(s, a); break;
+    default: launch_inv<8, INV>(s, a); break;
+  }
 }
 
 void launch_small_reg_inverse(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int draw,
@@ -527,16 +620,17 @@ void launch_small_reg_inverse(hipStream_t s, const double* X, int n, int d, cons
   a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
   a.draw0 = draw; a.B = 1; a.sigma2 = sigma2; a.mode = 0; a.tau2 = 0.0;
   a.loglik = loglik; a.beta = beta; a.status = status; a.Rinv = Rinv; a.m = 0; a.S = 1;
-  switch ((n + 15) / 16) {
-    case 1: launch_inv<1>(s, a); break;
-    case 2: launch_inv<2>(s, a); break;
-    case 3: launch_inv<3>(s, a); break;
-    case 4: launch_inv<4>(s, a); break;
-    case 5: launch_inv<5>(s, a); break;
-    case 6: launch_inv<6>(s, a); break;
-    case 7: launch_inv<7>(s, a); break;
-    default: launch_inv<8>(s, a); break;
-  }
+  dispatch_inv<1>(s, a);
+}
+
+// d loglik / d params for B draws (ccgp_loglik_grad_batch, n <= 128): one workgroup per draw on the same scheme
+void launch_small_reg_grad(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv, int B,
+                           double sigma2, double* loglik, double* beta, double* grad, int* status) {
+  RegArgs a{};
+  a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
+  a.draw0 = 0; a.B = B; a.sigma2 = sigma2; a.mode = 0; a.tau2 = 0.0;
+  a.loglik = loglik; a.beta = beta; a.status = status; a.grad = grad; a.Btot = B; a.m = 0; a.S = 1;
+  dispatch_inv<2>(s, a);
 }
 
 bool small_reg_supported(int n, int d, int K, bool per_design, bool predict) {

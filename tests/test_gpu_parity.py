@@ -617,6 +617,33 @@ def test_gradient_matches_finite_differences(handle, case):
         np.testing.assert_allclose(grad[b], fd, rtol=tol, atol=tol * np.abs(fd).max())
 
 
+def test_register_resident_gradient_wide_design_three_components_and_a_failed_draw(handle):
+    """The n <= 128 gradient (round 3: `small_reg_kernel<16, NB, NB + 1, gradient>`) beyond the reference's shapes:
+    d = 20 (two groups of 16 per-dimension accumulators), K = 3, n = 45 (not a multiple of 16), a batch in which one
+    draw is exactly singular (all scales 0: R = 11'), and agreement with the in-LDS kernel it replaced."""
+    from ccgp_amd import api
+    rng = np.random.default_rng(31)
+    n, d, K = 45, 20, 3
+    X = rng.random((n, d))
+    y = np.sin(3 * X[:, 0]) + X[:, 1:4].sum(axis=1)
+    rows = np.stack([np.concatenate([[0.5, 0.3, 0.2], rng.uniform(0.05, 0.3, d), rng.uniform(0.5, 1.5, d), rng.uniform(3.0, 6.0, d)])
+                     for _ in range(4)])
+    rows[2, K:] = 0.0
+    ll, beta, grad, st = handle.loglik_grad_batch(X, y, K, rows, 2.0)
+    assert list(st != 0) == [False, False, True, False] and np.isnan(grad[2]).all() and np.isnan(ll[2])
+    for b in (0, 1, 3):
+        w, Th = orc.unpack_params(rows[b], K, d)
+        assert ll[b] == pytest.approx(orc.loglik_general(X, y, w, Th, 2.0)[0], rel=1e-9)
+        fd = orc.loglik_grad_fd(X, y, rows[b], K, d, 2.0)
+        np.testing.assert_allclose(grad[b], fd, rtol=2e-5, atol=2e-5 * np.abs(fd).max())
+    handle.set_option(api.OPT_SMALL_LDS, 1)                 # the in-LDS kernel of rounds 1-2
+    try:
+        _, _, g_lds, _ = handle.loglik_grad_batch(X, y, K, rows[[0, 1, 3]], 2.0)
+    finally:
+        handle.set_option(api.OPT_SMALL_LDS, 0)
+    np.testing.assert_allclose(grad[[0, 1, 3]], g_lds, rtol=1e-9, atol=1e-12 * np.abs(g_lds).max())
+
+
 # ------------------------------------------------------------------------------- 8(f)-4 entropy criteria
 def test_entropy_criteria_over_candidate_designs(handle):
     """Batch Sequential ME Design.R:856-877: -det(R.mixed) for candidate designs, and the augmented

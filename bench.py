@@ -695,6 +695,23 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
                   "value": 1.0 / lat[True], "unit": "logpost calls/s (sequential, with R.Inv)",
                   "us_per_call_with_Rinv": 1e6 * lat[True], "us_per_call_value_only": 1e6 * lat[False], "calls": calls,
                   "cpu": cpu_sec.get("logpost")})
+    # the north_star's "+ gradient": ccgp_loglik_grad_batch (host pointers) on the Heat-Exchanger design, next to the
+    # same call without the gradient
+    Bg = 65536
+    Pg = P2[:Bg]
+    h.loglik_grad_batch(X2, y2, K2, Pg, s22)
+    t1 = time.perf_counter()
+    _, _, gg, stg = h.loglik_grad_batch(X2, y2, K2, Pg, s22)
+    t_g = time.perf_counter() - t1
+    h.loglik_batch(X2, y2, K2, Pg, s22)
+    t1 = time.perf_counter()
+    h.loglik_batch(X2, y2, K2, Pg, s22)
+    t_l = time.perf_counter() - t1
+    items.append({"workload": "gradient: Qian n=64, %d draws, log-likelihood + d/d(w, theta) through ccgp_loglik_grad_batch "
+                              "(host pointers, PCIe-inclusive)" % Bg,
+                  "value": Bg / t_g, "unit": "gradients/s", "ms_per_call": 1e3 * t_g,
+                  "ms_same_call_without_gradient": 1e3 * t_l, "failed": int((stg != 0).sum()),
+                  "all_finite": bool(np.isfinite(gg).all()), "cpu": None})
     # prediction at a second test set from factors kept in HBM, against re-factorising
     if args.workload == "cfg4" and X.shape[0] == 4096:
         Sf, mf_ = CFG4_PREDICT_DRAWS, CFG4_PREDICT_SITES

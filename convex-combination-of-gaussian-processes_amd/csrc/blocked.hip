@@ -35,6 +35,10 @@ namespace ccgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#ifndef CCGP_UPDATE_IL
+#define CCGP_UPDATE_IL 1   // whole update tiles through tile_accumulate_il (0: the round-2 loop, for A/B builds)
+#endif
+
 namespace {
 
 
@@ -221,6 +225,137 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
 }
 
 
+
+// ---- whole update tile, round-3 loop ("interleaved") ----------------------------------------------------
+// tests/hip/update_loop_probe.hip rebuilt the loop above with its ingredients switchable and found where the 15 % of
+// non-MFMA cycles go (MI355X, steady state, no epilogue): bare MFMAs 77.5 TFLOP/s; + the 32 ds_read_b64 fragment
+// loads of a stage 71 - 74; + the eight global_load_lds with their per-lane 64-bit address arithmetic 67 - 71.  Three
+// changes bring the full loop back to 75.5 - 76.5:
+//   * the four 16 x 16 sub-tiles of a wave interleave their rows (sub-tile y holds rows row0 + 4 l15 + y, sub-tile x
+//     columns col0 + 4 i + x), so a lane's four P (or Q) fragments of a k-step are 32 CONTIGUOUS bytes of the
+//     linear LDS image: two ds_read_b128 instead of four ds_read_b64, conflict-free without the XOR swizzle;
+//   * the stage requests are buffer_load ... lds: the lane offset is ONE constant 32-bit VGPR, rows and stages
+//     advance in SGPRs (soffset) -- no vector instruction between the MFMAs;
+//   * fragment reads and stage requests are dealt out one per MFMA (an MFMA holds its pipe for 64 cycles during
+//     which the wave issues the next request for free) instead of in bursts.
+// Every output element still accumulates its k-sum four at a time in ascending order: the bits are those of
+// gemm_accumulate, whatever the sub-tile a row or column lands in (ring strips, trsm and the diagonal workgroup
+// keep the older loop).
+//   acc[x][y] register r  =  element (row0 + 4 l15 + y,  col0 + 4 (l4 + 4 r) + x)  of the 128 x 128 tile.
+__device__ __forceinline__ void tile_accumulate_il(double* smem, const double* P, int ldP, const double* Q,
+                                                   int ldQ, int Kdim, d4 (&acc)[4][4]) {
+  constexpr int BKs = 16, STAGE = 2 * BKs * kTile;     // doubles per stage: P image [16][128], then Q image [16][128]
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 64;
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // wave w requests rows k = w + 4 q of either image: one wave-instruction = one 1 KiB row, lane-linear
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, -1, 0x00020000);
+  const unsigned lane_b = (unsigned)lane * 16;
+  const unsigned stepP = (unsigned)ldP * 32, stepQ = (unsigned)ldQ * 32;   // four rows, bytes
+  unsigned oP = (unsigned)wave * (unsigned)ldP * 8, oQ = (unsigned)wave * (unsigned)ldQ * 8;
+  auto request = [&](int stage, int r) {   // r = 0..3: P rows, 4..7: Q rows
+    double* dst = smem + stage * STAGE + (r >> 2) * (BKs * kTile) + (wave + 4 * (r & 3)) * kTile;
+    if (r < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)dst, 16, lane_b,
+                                               oP + (unsigned)(r & 3) * stepP, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ, (__attribute__((address_space(3))) void*)dst, 16, lane_b,
+                                               oQ + (unsigned)(r & 3) * stepQ, 0, 0);
+  };
+  auto advance = [&]() { oP += 4 * stepP; oQ += 4 * stepQ; };
+
+  const int pofs = l4 * kTile + row0 + 4 * l15, qofs = BKs * kTile + l4 * kTile + col0 + 4 * l15;
+  double pfA[4], qfA[4], pfB[4], qfB[4];
+#define CCGP_SB __builtin_amdgcn_sched_barrier(0)
+#define CCGP_ILOAD(PF, QF, STG, KK, I)                                                            \
+  do {                                                                                           \
+    const double* St_ = smem + (STG) * STAGE + (KK) * 4 * kTile;                                 \
+    if ((I) == 0) { const d2 v_ = *(const d2*)(St_ + pofs); PF[0] = v_[0]; PF[1] = v_[1]; }      \
+    if ((I) == 1) { const d2 v_ = *(const d2*)(St_ + pofs + 2); PF[2] = v_[0]; PF[3] = v_[1]; }  \
+    if ((I) == 2) { const d2 v_ = *(const d2*)(St_ + qofs); QF[0] = v_[0]; QF[1] = v_[1]; }      \
+    if ((I) == 3) { const d2 v_ = *(const d2*)(St_ + qofs + 2); QF[2] = v_[0]; QF[3] = v_[1]; }  \
+  } while (0)
+// one k-step: 16 MFMAs; behind MFMA i < 4 the i-th fragment read of the NEXT k-step (LD), behind MFMA i < 8 of a
+// stage's last k-step the i-th request of the stage after next (RQ)
+#define CCGP_ISTEP(PFc, QFc, PFn, QFn, STGn, KKn, LD, RQ, STGr)                                   \
+  do {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                             \
+      acc[i >> 2][i & 3] =                                                                       \
+          __builtin_amdgcn_mfma_f64_16x16x4f64(QFc[i >> 2], PFc[i & 3], acc[i >> 2][i & 3], 0, 0, 0); \
+      if ((LD) && i < 4) CCGP_ILOAD(PFn, QFn, STGn, KKn, i);                                     \
+      if ((RQ) && i < 8) request(STGr, i);                                                       \
+      CCGP_SB;                                                                                   \
+    }                                                                                            \
+  } while (0)
+#define CCGP_ISTAGE(MORE, REFILL)                                                                 \
+  do {                                                                                           \
+    const int stg = kt & 1;                                                                      \
+    CCGP_ISTEP(pfA, qfA, pfB, qfB, stg, 1, true, false, 0);                                      \
+    CCGP_ISTEP(pfB, qfB, pfA, qfA, stg, 2, true, false, 0);                                      \
+    CCGP_ISTEP(pfA, qfA, pfB, qfB, stg, 3, true, false, 0);                                      \
+    if (MORE) {                                                                                  \
+      __syncthreads();          /* stage kt read by everyone (its last fragments are in registers), kt+1 landed */ \
+      CCGP_SB;                                                                                   \
+    }                                                                                            \
+    CCGP_ISTEP(pfB, qfB, pfA, qfA, stg ^ 1, 0, MORE, REFILL, stg);                               \
+    if (REFILL) advance();                                                                       \
+  } while (0)
+
+  const int nk = Kdim / BKs;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) request(0, r);
+  advance();
+  __syncthreads();   // drains the requests (vmcnt(0)) and publishes the stage
+  if (nk > 1) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) request(1, r);
+    advance();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) CCGP_ILOAD(pfA, qfA, 0, 0, i);
+  CCGP_SB;
+  int kt = 0;
+  for (; kt < nk - 2; ++kt) CCGP_ISTAGE(true, true);
+  if (nk >= 2) { CCGP_ISTAGE(true, false); ++kt; }
+  CCGP_ISTAGE(false, false);
+#undef CCGP_ISTAGE
+#undef CCGP_ISTEP
+#undef CCGP_ILOAD
+#undef CCGP_SB
+}
+
+// C -= acc for a whole update tile in the interleaved sub-tile map: a lane holds four CONTIGUOUS rows of each of
+// its 16 columns, so the read-modify-write is 16 + 16 32-byte accesses per lane (64 + 64 of 8 bytes before)
+__device__ __forceinline__ void update_tile_il(double* smem, const double* P, int ldP, const double* Q, int ldQ,
+                                               int Kdim, double* C, int ld) {
+  d4 acc[4][4];
+  tile_accumulate_il(smem, P, ldP, Q, ldQ, Kdim, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 64;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double* Cl = C + row0 + 4 * l15 + (size_t)(col0 + 4 * l4) * ld;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    d4 cv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cv[r] = *(const d4*)(Cl + (size_t)(16 * r + x) * ld);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d4 o;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) o[y] = cv[r][y] - acc[x][y][r];
+      *(d4*)(Cl + (size_t)(16 * r + x) * ld) = o;
+    }
+  }
+}
 
 // ---- half-width strip with a four-stage ring (tail of an update launch) ---------------------------
 // Same strip geometry, fragments and per-accumulator MFMA order as gemm_accumulate<2, false> (so the same
@@ -736,6 +871,10 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   }
   if constexpr (MODE == 0 && S == 1) {
     if (ring) { gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
+#if CCGP_UPDATE_IL
+    update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
+    return;
+#endif
   }
   gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
 }

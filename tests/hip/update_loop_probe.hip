@@ -286,5 +286,29 @@ int main() {
   run2<true, 2, true>("il: lds b128 + dma (16 share)", panels, panel_stride, ld, nk, out, 16);
   run2<true, 3, false>("il: lds + buffer dma (16 share)", panels, panel_stride, ld, nk, out, 16);
   run2<true, 3, true>("il: lds b128 + buffer dma (16 sh)", panels, panel_stride, ld, nk, out, 16);
+  // sustained: do the clocks hold over the length of a whole 512-matrix sweep (~200 ms)?
+  {
+    hipFuncSetAttribute((const void*)probe2<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE * 8);
+    hipEvent_t e[9];
+    for (int i = 0; i < 9; ++i) hipEventCreate(&e[i]);
+    for (int which = 0; which < 2; ++which) {
+      hipDeviceSynchronize();
+      hipEventRecord(e[0]);
+      for (int seg = 0; seg < 8; ++seg) {
+        for (int i = 0; i < 8; ++i) {
+          if (which == 0) hipLaunchKernelGGL((probe<false, false, 0>), dim3(512), dim3(256), 2 * STAGE * 8, 0, panels, panel_stride, ld, nk, out, 1);
+          else hipLaunchKernelGGL((probe2<true, 3, true>), dim3(512), dim3(256), 2 * STAGE * 8, 0, panels, panel_stride, ld, nk, out, 16);
+        }
+        hipEventRecord(e[seg + 1]);
+      }
+      hipEventSynchronize(e[8]);
+      printf("sustained %s, TFLOP/s per ~57 ms segment:", which == 0 ? "mfma only" : "full loop (il b128 + buffer dma)");
+      for (int seg = 0; seg < 8; ++seg) {
+        float t; hipEventElapsedTime(&t, e[seg], e[seg + 1]);
+        printf(" %.1f", 8.0 * 512 * 4 * (double)nk * 64 * 2048.0 / t / 1e9);
+      }
+      printf("\n");
+    }
+  }
   return 0;
 }

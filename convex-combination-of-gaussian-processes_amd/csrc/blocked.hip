@@ -35,6 +35,9 @@ namespace ccgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#ifndef CCGP_DIAG_V2
+#define CCGP_DIAG_V2 1   // per-wave specialised k-loop of the diagonal workgroup (0: the round-2 loop, for A/B builds)
+#endif
 #ifndef CCGP_UPDATE_IL
 #define CCGP_UPDATE_IL 1   // whole update tiles through tile_accumulate_il (0: the round-2 loop, for A/B builds)
 #endif
@@ -495,6 +498,107 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
 }
 
 
+// k-loop of the diagonal workgroup (see diag_rhs_tile below), one instantiation per wave W so that everything a
+// slot needs is a compile-time constant.  Against the round-2 loop (kept under CCGP_DIAG_V2 = 0):
+//   * both operands come from the SAME panel image and the MFMA's A and B lane maps coincide (lane & 15 -> index,
+//     lane >> 4 -> k), so the fragment of block row r IS the fragment of column block r: a k-step loads the column
+//     blocks 0 .. max(W, 7 - W) once (plus 2W, 2W + 1 for the right-hand sides where they lie beyond, plus the
+//     right-hand-side rows): 7 - 9 ds_reads for 11 MFMAs instead of 14, and no v_cndmask to pick a row fragment;
+//   * stage requests are buffer_load ... lds (constant lane offset, rows advance in SGPRs);
+//   * reads and requests are dealt out one per MFMA (tests/hip/update_loop_probe.hip).
+// Slot s of acc keeps its meaning (s <= W: block row W x column block s; s <= 8: block row 7 - W x column block
+// s - W - 1; 9, 10: right-hand-side rows x column blocks 2W, 2W + 1) and every element its k order: same bits.
+template <int W>
+__device__ __forceinline__ void diag_rhs_accumulate(double* smem, const double* Qp, const double* Tp, int ld,
+                                                    int Kdim, d4 (&acc)[11]) {
+  constexpr int BKs = 16, TR = 16, STAGE = BKs * kTile + BKs * TR;
+  constexpr int RA = W, RB = 7 - W;
+  constexpr int CBMAX = RA > RB ? RA : RB;
+  constexpr bool XTRA = 2 * W + 1 > CBMAX;             // W = 3: right-hand sides against column blocks 6, 7
+  constexpr int NQ = CBMAX + 1 + (XTRA ? 2 : 0);       // panel fragments per k-step; fragment NQ = right-hand-side rows
+  constexpr int NR = W < 2 ? 5 : 4;                    // stage requests of this wave (waves 0, 1 also stage T)
+  auto frag_of = [](int cb) constexpr { return cb <= CBMAX ? cb : CBMAX + 1 + (cb - 2 * W); };
+  auto cb_of_frag = [](int f) constexpr { return f <= CBMAX ? f : 2 * W + (f - CBMAX - 1); };
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, sw = l4 & 1;
+
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)Tp, 0, -1, 0x00020000);
+  // panel rows k = W + 4 q, swizzled source (the 16-row block index of row k is XORed with k & 1 = W & 1)
+  const unsigned lane_q = (unsigned)(((((lane >> 3) ^ (W & 1)) << 4) + ((lane & 7) << 1)) * 8);
+  const unsigned lane_t = (unsigned)((((lane & 7) << 1) + (size_t)(lane >> 3) * ld) * 8);   // 8 columns x 16 rows
+  const unsigned stepQ = (unsigned)ld * 32;
+  unsigned oQ = (unsigned)W * (unsigned)ld * 8, oT = (unsigned)(8 * W) * (unsigned)ld * 8;
+  auto request = [&](int stage, int r) {
+    double* St_ = smem + stage * STAGE;
+    if (r < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ, (__attribute__((address_space(3))) void*)(St_ + (W + 4 * r) * kTile),
+                                               16, lane_q, oQ + (unsigned)r * stepQ, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rT, (__attribute__((address_space(3))) void*)(St_ + BKs * kTile + W * 8 * TR),
+                                               16, lane_t, oT, 0, 0);
+  };
+  auto advance = [&]() { oQ += 4 * stepQ; oT += (unsigned)BKs * (unsigned)ld * 8; };
+
+  int off[NQ];
+#pragma unroll
+  for (int f = 0; f < NQ; ++f) off[f] = l4 * kTile + ((cb_of_frag(f) ^ sw) << 4) + l15;
+  const int offT = BKs * kTile + l4 * TR + l15;
+  double fA[NQ + 1], fB[NQ + 1];
+#define CCGP_SB __builtin_amdgcn_sched_barrier(0)
+#define CCGP_DLOAD1(F, STG, KK, I)                                                                \
+  do {                                                                                           \
+    const double* St_ = smem + (STG) * STAGE;                                                    \
+    if ((I) < NQ) F[I] = St_[(KK) * 4 * kTile + off[(I) < NQ ? (I) : 0]];                        \
+    else F[NQ] = St_[(KK) * 4 * TR + offT];                                                      \
+  } while (0)
+#define CCGP_DSTEP(Fc, Fn, STGn, KKn, LD, RQ, STGr)                                               \
+  do {                                                                                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < 11; ++s_) {                                          \
+      const int cb_ = s_ >= 9 ? 2 * W + (s_ - 9) : (s_ <= W ? s_ : s_ - W - 1);                  \
+      const double pf_ = s_ >= 9 ? Fc[NQ] : (s_ <= W ? Fc[frag_of(RA)] : Fc[frag_of(RB)]);       \
+      acc[s_] = __builtin_amdgcn_mfma_f64_16x16x4f64(Fc[frag_of(cb_)], pf_, acc[s_], 0, 0, 0);   \
+      if ((LD) && s_ <= NQ) CCGP_DLOAD1(Fn, STGn, KKn, s_);                                      \
+      if ((RQ) && s_ < NR) request(STGr, s_);                                                    \
+      CCGP_SB;                                                                                   \
+    }                                                                                            \
+  } while (0)
+#define CCGP_DSTAGE(MORE, REFILL)                                                                 \
+  do {                                                                                           \
+    const int stg = kt & 1;                                                                      \
+    CCGP_DSTEP(fA, fB, stg, 1, true, false, 0);                                                  \
+    CCGP_DSTEP(fB, fA, stg, 2, true, false, 0);                                                  \
+    CCGP_DSTEP(fA, fB, stg, 3, true, false, 0);                                                  \
+    if (MORE) {                                                                                  \
+      __syncthreads();                                                                           \
+      CCGP_SB;                                                                                   \
+    }                                                                                            \
+    CCGP_DSTEP(fB, fA, stg ^ 1, 0, MORE, REFILL, stg);                                           \
+    if (REFILL) advance();                                                                       \
+  } while (0)
+
+  const int nk = Kdim / BKs;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) request(0, r);
+  advance();
+  __syncthreads();
+  if (nk > 1) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) request(1, r);
+    advance();
+  }
+#pragma unroll
+  for (int i = 0; i <= NQ; ++i) CCGP_DLOAD1(fA, 0, 0, i);
+  CCGP_SB;
+  int kt = 0;
+  for (; kt < nk - 2; ++kt) CCGP_DSTAGE(true, true);
+  if (nk >= 2) { CCGP_DSTAGE(true, false); ++kt; }
+  CCGP_DSTAGE(false, false);
+#undef CCGP_DSTAGE
+#undef CCGP_DSTEP
+#undef CCGP_DLOAD1
+#undef CCGP_SB
+}
+
 // ---- diagonal tile of the update, fused with the right-hand-side rows ---------------------------
 // The diagonal tile T_jj = A_jj - L_j L_j' (L_j = the finished panel, rows j of block columns < j)
 // needs only its lower triangle: 36 of its 64 16 x 16 sub-tiles, and both GEMM operands are the SAME
@@ -509,7 +613,7 @@ __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, co
                                               int Kdim, double* C, double* Ct) {
   constexpr int BKs = 16;
   constexpr int TR = 16;                                // right-hand-side rows staged
-  constexpr int STAGE = BKs * kTile + BKs * TR;         // doubles per stage
+  [[maybe_unused]] constexpr int STAGE = BKs * kTile + BKs * TR;         // doubles per stage
   constexpr int NS = 11;                                // sub-tiles per wave: 9 of the triangle + 2 right-hand-side
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -528,6 +632,14 @@ __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, co
   cbs[9] = 2 * wave;
   cbs[10] = 2 * wave + 1;
 
+#if CCGP_DIAG_V2
+  switch (wave) {
+    case 0: diag_rhs_accumulate<0>(smem, Qp, Tp, ld, Kdim, acc); break;
+    case 1: diag_rhs_accumulate<1>(smem, Qp, Tp, ld, Kdim, acc); break;
+    case 2: diag_rhs_accumulate<2>(smem, Qp, Tp, ld, Kdim, acc); break;
+    default: diag_rhs_accumulate<3>(smem, Qp, Tp, ld, Kdim, acc); break;
+  }
+#else
   const int psrc = ((((lane >> 3) ^ (wave & 1)) << 4) + ((lane & 7) << 1));
   const double* pQ = Qp + psrc + (size_t)wave * ld;                       // wave w stages columns k = w + 4q
   const double* pT = Tp + ((lane & 7) << 1) + (size_t)(8 * wave + (lane >> 3)) * ld;   // waves 0, 1: 8 columns each
@@ -603,6 +715,7 @@ __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, co
   }
 #undef CCGP_DLOADF
 #undef CCGP_DMFMAS
+#endif   // CCGP_DIAG_V2
 
   // C -= acc: all loads of a group before its stores (see gemm_tile)
 #pragma unroll

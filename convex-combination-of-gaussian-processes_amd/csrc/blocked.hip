@@ -67,6 +67,7 @@ struct GemmArgs {
   // (diag_factor) while the other tiles of the launch are still being updated
   int fuse_diag;
   int tail_strips;   // host switch (CCGP_OPT_TAIL_STRIPS)
+  int wide;          // host switch (CCGP_OPT_WIDE_OFFSETS): 64-bit-pointer loops everywhere
   int n_s1;   // update, S = 1 kernel: tiles [0, n_s1) (dispatch order) run whole, the rest as two ring-pipelined strips
   double* logdet_part;
   int* status;
@@ -228,6 +229,12 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
 }
 
 
+
+// buffer_load ... lds addresses a panel as base + 32-bit offset: rows k < Kdim (+ the 16 of a stage in flight),
+// leading dimension ld, 8-byte elements, plus a lane's 1 KiB
+__device__ __forceinline__ bool fits_buffer_offsets(int Kdim, int ld) {
+  return ((size_t)Kdim + 32) * (size_t)ld * 8 < 0xFFFF0000ull;
+}
 
 // ---- whole update tile, round-3 loop ("interleaved") ----------------------------------------------------
 // tests/hip/update_loop_probe.hip rebuilt the loop above with its ingredients switchable and found where the 15 % of
@@ -610,7 +617,7 @@ __device__ __forceinline__ void diag_rhs_accumulate(double* smem, const double* 
 // sides as a separate "thin" workgroup that occupied a full slot for a whole tile time: at the late
 // block columns (few tile rows per matrix) half of the resident workgroups did almost no arithmetic.
 __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, const double* Tp, int ld,
-                                              int Kdim, double* C, double* Ct) {
+                                              int Kdim, double* C, double* Ct, int wide) {
   constexpr int BKs = 16;
   constexpr int TR = 16;                                // right-hand-side rows staged
   [[maybe_unused]] constexpr int STAGE = BKs * kTile + BKs * TR;         // doubles per stage
@@ -632,14 +639,16 @@ __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, co
   cbs[9] = 2 * wave;
   cbs[10] = 2 * wave + 1;
 
-#if CCGP_DIAG_V2
-  switch (wave) {
-    case 0: diag_rhs_accumulate<0>(smem, Qp, Tp, ld, Kdim, acc); break;
-    case 1: diag_rhs_accumulate<1>(smem, Qp, Tp, ld, Kdim, acc); break;
-    case 2: diag_rhs_accumulate<2>(smem, Qp, Tp, ld, Kdim, acc); break;
-    default: diag_rhs_accumulate<3>(smem, Qp, Tp, ld, Kdim, acc); break;
-  }
-#else
+  // the specialised loop addresses its panel through 32-bit buffer offsets: matrices whose panel spans 4 GiB or
+  // more (n >= ~16 000 with the identity rows of an inverse below them) keep the 64-bit-pointer loop -- same bits
+  if (CCGP_DIAG_V2 && !wide && fits_buffer_offsets(Kdim, ld)) {
+    switch (wave) {
+      case 0: diag_rhs_accumulate<0>(smem, Qp, Tp, ld, Kdim, acc); break;
+      case 1: diag_rhs_accumulate<1>(smem, Qp, Tp, ld, Kdim, acc); break;
+      case 2: diag_rhs_accumulate<2>(smem, Qp, Tp, ld, Kdim, acc); break;
+      default: diag_rhs_accumulate<3>(smem, Qp, Tp, ld, Kdim, acc); break;
+    }
+  } else {
   const int psrc = ((((lane >> 3) ^ (wave & 1)) << 4) + ((lane & 7) << 1));
   const double* pQ = Qp + psrc + (size_t)wave * ld;                       // wave w stages columns k = w + 4q
   const double* pT = Tp + ((lane & 7) << 1) + (size_t)(8 * wave + (lane >> 3)) * ld;   // waves 0, 1: 8 columns each
@@ -715,7 +724,7 @@ __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, co
   }
 #undef CCGP_DLOADF
 #undef CCGP_DMFMAS
-#endif   // CCGP_DIAG_V2
+  }
 
   // C -= acc: all loads of a group before its stores (see gemm_tile)
 #pragma unroll
@@ -896,7 +905,7 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
       if (b >= g.nb) return;
       double* Ab = g.A + (size_t)b * g.a_stride;
       diag_rhs_tile(smem, Ab + (size_t)g.j * kTile, Ab + g.npad, ld, g.j * kTile,
-                    Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld);
+                    Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld, g.wide);
       if (g.fuse_diag) {
         // T_jj went to memory through this CU's L1; the waves of the workgroup read it back in diag_factor's
         // thread layout.  All waves of a workgroup share that L1, so workgroup scope is enough: __syncthreads is
@@ -984,10 +993,10 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   }
   if constexpr (MODE == 0 && S == 1) {
     if (ring) { gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
-#if CCGP_UPDATE_IL
-    update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
-    return;
-#endif
+    if (CCGP_UPDATE_IL && !g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
+      update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
+      return;
+    }
   }
   gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
 }
@@ -1456,7 +1465,7 @@ struct GroupRun {
     g.A = w.A; g.a_stride = w.a_stride; g.npad = npad; g.invd = w.invd;
     g.invd_stride = (size_t)nt * kTile * kTile; g.nt = nt; g.nb = nb; g.ld = w.ld; g.ne = w.ne;
     g.extra_lower = job && job->kind >= kJobInverse ? 1 : 0;
-    g.fuse_diag = h->opt_fuse_diag; g.tail_strips = h->opt_tail_strips; g.logdet_part = w.z; g.status = status + b0; g.n = n;
+    g.fuse_diag = h->opt_fuse_diag; g.tail_strips = h->opt_tail_strips; g.wide = h->opt_wide_offsets; g.logdet_part = w.z; g.status = status + b0; g.n = n;
     dg.A = w.A; dg.a_stride = w.a_stride; dg.npad = npad; dg.invd = w.invd;
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;

@@ -420,6 +420,10 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) {
     h->opt_fuse_diag = value;
     return CCGP_OK;
   }
+  if (option == CCGP_OPT_WIDE_OFFSETS && (value == 0 || value == 1)) {
+    h->opt_wide_offsets = value;
+    return CCGP_OK;
+  }
   return fail(h, CCGP_EINVAL, "ccgp_set_option: unknown option or value");
 }
 

@@ -66,6 +66,7 @@ struct ccgp_handle {
   int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
+  int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
   // grow-only device scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;

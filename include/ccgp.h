@@ -100,8 +100,12 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *   CCGP_OPT_FUSE_DIAG      1 (default) = the update launch's diagonal-tile workgroup also factorises and inverts
  *                           the diagonal block; 0 = a separate diag_kernel launch per block column
  *   CCGP_OPT_TAIL_STRIPS    1 (default) = the tiles of an update launch's last, partial step of 256 workgroups run
- *                           as two half-width strips each; 0 = every tile whole */
-enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3 };
+ *                           as two half-width strips each; 0 = every tile whole
+ *   CCGP_OPT_WIDE_OFFSETS   0 (default) = the update loops address their panels through 32-bit buffer offsets wherever a
+ *                           panel spans less than 4 GiB; 1 = always the 64-bit-pointer loops that larger matrices
+ *                           fall back to (same bits: the tests hold one against the other) */
+enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3,
+       CCGP_OPT_WIDE_OFFSETS = 4 };
 int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);

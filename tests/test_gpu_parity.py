@@ -434,6 +434,41 @@ def test_gradient_at_n4096_matches_central_differences_of_the_device_likelihood(
     print("n=4096 gradient (1 draw, host API incl. allocation): %.1f ms" % (1e3 * t_grad))
 
 
+@pytest.mark.parametrize("n", [300, 1100])
+def test_update_loops_with_buffer_offsets_and_with_pointers_give_the_same_bits(handle, n):
+    """The round-3 update loops (whole tiles, diagonal workgroup) address their panels through 32-bit buffer offsets and
+    fall back to the 64-bit-pointer loops of round 2 when a panel spans 4 GiB or more.  OPT_WIDE_OFFSETS forces the
+    fallback: log-likelihood, prediction (extra tile rows) and gradient (identity rows) must agree bit for bit."""
+    from ccgp_amd import api
+    d, K = 4, 2
+    X, y = synthetic_design(n, d, seed=3 * n)
+    rng = np.random.default_rng(n)
+    B = 9                                     # not a multiple of 8: ragged matrix groups
+    P = np.empty((B, K + K * d))
+    for b in range(B):
+        w = rng.dirichlet(np.ones(K))
+        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
+        th[-1] = np.maximum(th[-1], 40.0)
+        P[b] = np.concatenate([w, th.ravel()])
+    Xt = rng.random((130, d))
+    def run():
+        ll, beta, st = handle.loglik_batch(X, y, K, P, 1.3)
+        mean, var, _, st2 = handle.predict_batch(X, y, K, P[:3], Xt, 1.3)
+        _, _, grad, st3 = handle.loglik_grad_batch(X, y, K, P[:2], 1.3)
+        assert not st.any() and not st2.any() and not st3.any()
+        return ll, beta, mean, var, grad
+    got = run()
+    handle.set_option(api.OPT_WIDE_OFFSETS, 1)
+    try:
+        want = run()
+    finally:
+        handle.set_option(api.OPT_WIDE_OFFSETS, 0)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    w, Th = orc.unpack_params(P[0], K, d)
+    assert got[0][0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.3)[0], rel=1e-9)
+
+
 def test_small_and_blocked_agree_across_the_cutover(handle):
     """n = 128 runs the fused kernel, n = 129 the blocked one: appending one far-away,
     nearly independent point must change the likelihood by exactly its own marginal term."""

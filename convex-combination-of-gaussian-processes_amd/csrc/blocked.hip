@@ -16,9 +16,16 @@
 // At 128-wide tiles that is 16 flop per HBM byte against a machine balance of ~10: MFMA-bound, with HBM at a
 // third of its peak.
 //
+// Two generations of k-loop live here.  Round 3 (tile_accumulate_il for whole update tiles, diag_rhs_accumulate<W> for
+// the diagonal workgroup): ds_read_b128 fragments on row-interleaved sub-tiles, buffer_load ... lds stage requests,
+// one request per MFMA -- 75 TFLOP/s for the bare loop against 67 - 71 (tests/hip/update_loop_probe.hip).  Round 2
+// (gemm_accumulate, strip_accumulate_ring): the panel solve, the strips, R^-1 tiles, and the fallback of the new
+// loops when a panel spans 4 GiB or more.  Every loop sums a tile element's k four at a time in ascending order,
+// so they are interchangeable bit for bit.
+//
 // Schedule of an update launch (profiles/r02_update_schedule.md): a launch of W workgroups takes ceil(W / 256)
-// steps -- one workgroup per CU (one wave per SIMD) already keeps the four MFMA pipes 84 % busy, the second resident
-// workgroup only fills bubbles.  The diagonal workgroups (one per matrix: lower triangle + right-hand sides, then the
+// steps -- one workgroup per CU (one wave per SIMD) already keeps the four MFMA pipes busy (84 % in round 2, 97 % of
+// the bare-MFMA rate now), the second resident workgroup only fills bubbles.  The diagonal workgroups (one per matrix: lower triangle + right-hand sides, then the
 // block factorisation) are dispatched first; whole tiles follow; the <= 128 tiles of a partial last step run as two
 // ring-pipelined half-width strips each.
 //

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
     if (a.lower_tiles) {
       if (gi >= a.n || gj >= a.n) v = (gi == gj) ? 1.0 : 0.0;  // identity padding
     }
+#ifdef CCGP_ABL_COV_NOSTORE   // timing ablation only
+    if (v == 12345.678)
+#endif
     if (gi < rows_valid) out[gi + (size_t)gj * a.ldo] = v;
   }
 }

@@ -18,8 +18,12 @@ def table(path, nt=32, nb=64):
         if j == nt - 1: break
     return out
 if __name__ == '__main__':
-    tabs = [table(p) for p in sys.argv[1:]]
-    print('j | ' + ' | '.join(sys.argv[1:]))
+    args = sys.argv[1:]
+    nb = 512                       # matrices per launch (--nb 64 for the slice)
+    if args and args[0] == '--nb':
+        nb = int(args[1]); args = args[2:]
+    tabs = [table(p, nb=nb) for p in args]
+    print('j | ' + ' | '.join(args))
     for j in range(1, 32):
         print(j, ' | '.join('%7.1f us %5.1f TF %5d wg %s' % t[j] for t in tabs))
     print('total ms', [round(sum(v[0] for v in t.values()) / 1e3, 2) for t in tabs])

@@ -1070,17 +1070,20 @@ struct RhsArgs {
   int identity;   // extra rows = identity (inverse / gradient) instead of zeros (prediction)
 };
 
-// rows npad..npad+127 of every matrix: y' (zero beyond n), 1' (zero beyond n), zeros
-__global__ void rhs_rows_kernel(RhsArgs g) {
+// rows npad..npad+15 of every matrix: y' (zero beyond n), 1' (zero beyond n), 14 zero rows.  Only these 16 of the
+// tile row's 128 rows are ever read (the diagonal workgroup and the thin panel-solve tile stage 16 right-hand-side
+// rows; finish / alpha / predict read rows 0 and 1): writing all 128 was 2.1 GB and 0.45 ms per 512 matrices.
+// One workgroup = 16 columns x 16 rows.
+__global__ __launch_bounds__(256) void rhs_rows_kernel(RhsArgs g) {
   const int ld = g.ld;
   double* Ab = g.A + (size_t)blockIdx.y * g.a_stride;
-  const int c = blockIdx.x;            // one workgroup of 128 threads per column
-  const int r = threadIdx.x;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int r = threadIdx.x & 15;
   double v = 0.0;
   if (c < g.n) v = r == 0 ? g.y[c] : (r == 1 ? 1.0 : 0.0);
   Ab[g.npad + r + (size_t)c * ld] = v;
   // extra tile rows start as zeros (the cross-correlation kernel then fills rows < m, columns < n)
-  for (int e = g.npad + kTile + r; e < ld; e += kTile)
+  for (int e = g.npad + kTile + r; e < ld; e += 16)
     Ab[e + (size_t)c * ld] = (g.identity && e - (g.npad + kTile) == c) ? 1.0 : 0.0;
 }
 
@@ -1464,7 +1467,7 @@ struct GroupRun {
       ScopedTimer t(h, CCGP_T_COV, s);
       launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld, w.xpad);
       RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
-      hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad, nb), dim3(kTile), 0, s, ra);
+      hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad / 16, nb), dim3(256), 0, s, ra);
       if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site
         launch_cov_cross_batched(s, pr->Xtest, pr->m, X, n, d, dv, b0, nb, w.A + npad + kTile, w.a_stride,
                                  w.ld);

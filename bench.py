@@ -664,9 +664,12 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
         for (a1, a2, a3, n5, m5, o_m, o_v, o_b, o_s) in dsets:
             h.predict_batch_dev(a1, n5, 9, a2, 2, dP5, S5, a3, m5, float(1.0), o_m, o_v, o_b, o_s)
 
+    # column-major on the host already, as R hands its matrices over (no layout conversion inside the timed call)
+    sets_f, P5f = [(np.asfortranarray(a), b, np.asfortranarray(c_)) for (a, b, c_) in sets], np.asfortranarray(P5)
+
     def pass5_host():
-        for (Xs, ys, Xt) in sets:
-            h.predict_batch(Xs, ys, 2, P5, Xt, 1.0)
+        for (Xs, ys, Xt) in sets_f:
+            h.predict_batch(Xs, ys, 2, P5f, Xt, 1.0)
     el5 = timed_passes(torch, pass5)
     e2e5 = timed_passes(torch, pass5_host)
     items.append({"workload": "cfg5: Ground-Vibrations predictive tables, 17 sets x 1000 draws x (150|110) test points",
@@ -695,6 +698,47 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
                   "value": 1.0 / lat[True], "unit": "logpost calls/s (sequential, with R.Inv)",
                   "us_per_call_with_Rinv": 1e6 * lat[True], "us_per_call_value_only": 1e6 * lat[False], "calls": calls,
                   "cpu": cpu_sec.get("logpost")})
+    # The LITERAL prediction path of an unchanged script: predict.post once per (draw, test site) (HX:688: S x m calls per
+    # test set), each on one frame row with its n x n R.Inv (HX:655-663).  Round 3 bound it as two host-pointer calls
+    # (Mixed.corr.vec, then the arithmetic of HX:667-670: six pageable copies and two synchronisations); round 4 as ONE
+    # (ccgp_predict_post: one pinned copy each way), and r/ccgp.R's compare.GP / prediction wrappers bypass it altogether
+    # with one ccgp_predict_batch per test set (the cfg5 line above).  us per call, next to the batched cost per
+    # (draw, site) pair and to the other per-draw helpers factors.frame calls (factors HX:641, beta.MLE HX:458).
+    from ccgp_amd.rsurface import CombinedGP, pack_iso
+    lit = []
+    gv_X, gv_y, gv_Xt = sets[-1] if sets[-1][0].shape[0] == 90 else max(sets, key=lambda t: t[0].shape[0])
+    for name, (Xl, yl, xl, dl) in (("Qian n=64", (X2, y2, X2[:1] * 0.97, 4)), ("GV n=%d" % gv_X.shape[0], (gv_X, gv_y, gv_Xt[:1], 9))):
+        nl = Xl.shape[0]
+        gp = CombinedGP("GV", handle=h)
+        row = gp.factors_frame_from_draws([(0.7, 0.3, 15.0)], Xl, 10.0, yl)[0]
+        prow = pack_iso(0.7, 0.3, 15.0, dl)
+        beta_l, mf_l, v1_l, v2_l = row[3], row[4:4 + nl], row[4 + nl:4 + 2 * nl], row[4 + 2 * nl]
+        Rinv_l = np.asfortranarray(row[5 + 2 * nl:].reshape(nl, nl, order="F"))
+
+        def pair():
+            r = h.mixed_corr_cross(xl, Xl, 2, prow)
+            return h.predict_from_factors(r, beta_l, mf_l, v1_l, v2_l, Rinv_l, 10.0)
+
+        def fused():
+            return h.predict_post(xl, Xl, 2, prow, beta_l, mf_l, v1_l, v2_l, Rinv_l, 10.0)
+        timings = {}
+        for key, fn in (("two_calls", pair), ("one_call", fused), ("factors", lambda: h.factors(Rinv_l, beta_l, yl)),
+                        ("beta_mle", lambda: h.beta_mle(Rinv_l, yl))):
+            fn()
+            t1 = time.perf_counter()
+            for _ in range(calls):
+                fn()
+            timings[key] = 1e6 * (time.perf_counter() - t1) / calls
+        same = bool(np.array_equal(np.array(pair()), np.array(fused())))
+        lit.append({"design": name, "us_per_predict_post_two_calls": timings["two_calls"],
+                    "us_per_predict_post_one_call": timings["one_call"], "us_per_factors": timings["factors"],
+                    "us_per_beta_mle": timings["beta_mle"], "identical": same})
+    items.append({"workload": "literal predict.post latency (host pointers, one frame row with its R.Inv per call; HX:655-673)",
+                  "value": 1e6 / lit[-1]["us_per_predict_post_one_call"], "unit": "predict.post calls/s (sequential, GV n=90)",
+                  "per_design": lit, "calls": calls,
+                  "batched_ns_per_prediction_kernel": 1e9 * el5 / pairs, "batched_ns_per_prediction_end_to_end": 1e9 * e2e5 / pairs,
+                  "test_set_of_1000x150_literal_s": 1e-6 * lit[-1]["us_per_predict_post_one_call"] * 150000,
+                  "test_set_of_1000x150_batched_ms": 1e3 * e2e5 / len(sets), "cpu": None})
     # the north_star's "+ gradient": ccgp_loglik_grad_batch (host pointers) on the Heat-Exchanger design, next to the
     # same call without the gradient
     Bg = 65536

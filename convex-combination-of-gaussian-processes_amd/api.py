@@ -68,6 +68,8 @@ SIGNATURES = {
     "ccgp_factors": (c_int, [c_void_p, _dp, c_double, _dp, c_int, _dp]),
     "ccgp_predict_from_factors": (c_int, [c_void_p, _dp, c_int, c_int, c_double, _dp, _dp, c_double,
                                           _dp, c_double, _dp, _dp]),
+    "ccgp_predict_post": (c_int, [c_void_p, _dp, c_int, _dp, c_int, c_int, c_int, _dp, c_double, _dp, _dp, c_double,
+                                  _dp, c_double, _dp, _dp]),
     "ccgp_multi_create": (c_int, [c_int, _ip, POINTER(c_void_p)]),
     "ccgp_multi_destroy": (c_int, [c_void_p]),
     "ccgp_multi_count": (c_int, [c_void_p]),
@@ -403,6 +405,20 @@ class Handle:
         self._chk(lib().ccgp_predict_from_factors(self._h, _p(r), m, n, float(beta), _p(mf), _p(v1),
                                                   float(var_factor2), _p(R_inv), float(sigma2),
                                                   _p(mean), _p(var)))
+        return mean, var
+
+    def predict_post(self, Xnew, X, K, params_row, beta, mean_factor, var_factor1, var_factor2, R_inv, sigma2):
+        """Literal predict.post (HX:655-673) in one device round trip: Mixed.corr.vec for the rows of Xnew, then the
+        quadratic forms with the caller's cached terms.  Returns (mean[m], var[m])."""
+        X = _f(X)
+        n, d = X.shape
+        Xnew = _f(np.atleast_2d(Xnew))
+        m = Xnew.shape[0]
+        row = _f(params_row, (K + K * d,))
+        mf, v1, R_inv = _f(mean_factor, (n,)), _f(var_factor1, (n,)), _f(R_inv, (n, n))
+        mean, var = np.empty(m), np.empty(m)
+        self._chk(lib().ccgp_predict_post(self._h, _p(Xnew), m, _p(X), n, d, K, _p(row), float(beta), _p(mf), _p(v1),
+                                          float(var_factor2), _p(R_inv), float(sigma2), _p(mean), _p(var)))
         return mean, var
 
     # -- a8, a9, a12 --------------------------------------------------------------------

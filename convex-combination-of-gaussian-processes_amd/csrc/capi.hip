@@ -1,10 +1,12 @@
 // extern "C" surface of libccgp (include/ccgp.h).  Host orchestration only: argument
 // checks, device scratch, chunking of batches, and the handful of host-side scalars
 // (log-Jacobian, log-prior, quadrature nodes) that the reference computes in R.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <vector>
 
@@ -114,6 +116,103 @@ struct Carver {
     return p;
   }
 };
+
+// ---- host <-> device traffic of the host-pointer entry points ------------------------------------------------
+// The pieces of a call lie back to back in the handle's staging buffer (Carver).  A hipMemcpyAsync from / to
+// pageable memory is a staged, synchronous copy of its own (10 - 20 us each); what the reference's callers issue
+// are many SMALL calls (predict.post per draw and test site HX:688, beta.MLE / factors per draw HX:641), so up to
+// kPinMax the host image of the whole span is assembled in the handle's pinned buffer and crosses PCIe in ONE copy
+// each way; larger payloads are copied piece by piece as before.
+struct Piece {
+  void* dev;
+  void* host;      // source for push, destination for pull; nullptr: skip
+  size_t bytes;
+};
+constexpr size_t kPinMax = size_t(8) << 20;
+constexpr int kPullSlices = ccgp::kPullSlices;
+
+int push(ccgp_handle* h, std::initializer_list<Piece> ps) {
+  char *lo = nullptr, *hi = nullptr;
+  for (const Piece& p : ps) {
+    if (!p.host || !p.bytes) continue;
+    char* d = static_cast<char*>(p.dev);
+    if (!lo || d < lo) lo = d;
+    if (!hi || d + p.bytes > hi) hi = d + p.bytes;
+  }
+  h->pin_in = 0;
+  if (!lo) return CCGP_OK;
+  const size_t span = (size_t)(hi - lo);
+  if (span <= kPinMax && ensure_pin(h, span) == CCGP_OK) {
+    char* pin = static_cast<char*>(h->pin);
+    for (const Piece& p : ps)
+      if (p.host && p.bytes) std::memcpy(pin + (static_cast<char*>(p.dev) - lo), p.host, p.bytes);
+    CCGP_HIP(hipMemcpyAsync(lo, pin, span, hipMemcpyHostToDevice, h->stream));
+    h->pin_in = Carver::al(span);
+    return CCGP_OK;
+  }
+  for (const Piece& p : ps)
+    if (p.host && p.bytes) CCGP_HIP(hipMemcpyAsync(p.dev, p.host, p.bytes, hipMemcpyHostToDevice, h->stream));
+  return CCGP_OK;
+}
+
+// device -> host of the result pieces, then the stream is synchronised (the call's results are valid on return)
+int pull(ccgp_handle* h, std::initializer_list<Piece> ps) {
+  char *lo = nullptr, *hi = nullptr;
+  for (const Piece& p : ps) {
+    if (!p.host || !p.bytes) continue;
+    char* d = static_cast<char*>(p.dev);
+    if (!lo || d < lo) lo = d;
+    if (!hi || d + p.bytes > hi) hi = d + p.bytes;
+  }
+  if (!lo) {
+    CCGP_HIP(hipStreamSynchronize(h->stream));
+    return CCGP_OK;
+  }
+  const size_t span = (size_t)(hi - lo);
+  if (span <= kPinMax && ensure_pin(h, h->pin_in + span) == CCGP_OK) {
+    char* pin = static_cast<char*>(h->pin) + h->pin_in;
+    // a large result (the S x m tables of ccgp_predict_batch: 2.4 MB per Ground-Vibrations set) comes back in four
+    // slices, each followed by an event: the host copies slice c out of the pinned buffer while slice c + 1 is still
+    // crossing PCIe, instead of waiting for all of it and then copying all of it
+    const int nsl = span >= (size_t(512) << 10) ? kPullSlices : 1;
+    if (nsl > 1 && !h->pull_ev[0]) {
+      for (int c = 0; c < kPullSlices; ++c)
+        if (hipEventCreateWithFlags(&h->pull_ev[c], hipEventDisableTiming) != hipSuccess) {
+          for (int q = 0; q < c; ++q) (void)hipEventDestroy(h->pull_ev[q]);
+          h->pull_ev[0] = nullptr;
+          h->err = "hipEventCreateWithFlags failed";
+          return CCGP_EHIP;
+        }
+    }
+    const size_t step = ((span + nsl - 1) / nsl + 255) / 256 * 256;
+    for (int c = 0; c < nsl; ++c) {
+      const size_t a = std::min(span, (size_t)c * step), b = std::min(span, a + step);
+      if (b > a) CCGP_HIP(hipMemcpyAsync(pin + a, lo + a, b - a, hipMemcpyDeviceToHost, h->stream));
+      if (nsl > 1) CCGP_HIP(hipEventRecord(h->pull_ev[c], h->stream));
+    }
+    for (int c = 0; c < nsl; ++c) {
+      const size_t a = std::min(span, (size_t)c * step), b = std::min(span, a + step);
+      if (nsl > 1) CCGP_HIP(hipEventSynchronize(h->pull_ev[c]));
+      else CCGP_HIP(hipStreamSynchronize(h->stream));
+      for (const Piece& p : ps) {
+        if (!p.host || !p.bytes) continue;
+        const size_t p0 = (size_t)(static_cast<char*>(p.dev) - lo), p1 = p0 + p.bytes;
+        const size_t x0 = std::max(p0, a), x1 = std::min(p1, b);
+        if (x1 > x0) std::memcpy(static_cast<char*>(p.host) + (x0 - p0), pin + x0, x1 - x0);
+      }
+    }
+    return CCGP_OK;
+  }
+  for (const Piece& p : ps)
+    if (p.host && p.bytes) CCGP_HIP(hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, h->stream));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  return CCGP_OK;
+}
+
+template <class T>
+Piece piece(T* dev, const T* host, size_t count) {
+  return Piece{dev, const_cast<T*>(host), sizeof(T) * count};
+}
 
 bool bad_shape(int n, int d, int K) {
   return n < 1 || d < 1 || d > kMaxD || K < 1 || K > kMaxK;
@@ -369,6 +468,8 @@ int ccgp_destroy(ccgp_handle* h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->stage) (void)hipFree(h->stage);
   if (h->pin) (void)hipHostFree(h->pin);
+  for (auto& e : h->pull_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return CCGP_OK;
@@ -491,10 +592,8 @@ static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* 
   double* dXn = c.take<double>((size_t)m * d);
   double* dp = c.take<double>(P);
   double* dout = c.take<double>((size_t)m * n);
-  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
-  if (!gram)
-    CCGP_HIP(hipMemcpyAsync(dXn, Xnew, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dp, params_row, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+  if (int prc = push(h, {piece(dX, X, (size_t)n * d), piece(dXn, gram ? nullptr : Xnew, (size_t)m * d), piece(dp, params_row, P)}))
+    return prc;
   DrawView dv{dp, 1, K, d};
   dv.fam = h->fam;
   if (int frc = check_family(h, dv.fam, d, K)) return frc;
@@ -503,9 +602,7 @@ static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* 
     launch_cov_dense(h->stream, gram ? dX : dXn, m, dX, n, d, dv, 0, dout, m);
   }
   CCGP_LAUNCH_CHECK();
-  CCGP_HIP(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipStreamSynchronize(h->stream));
-  return CCGP_OK;
+  return pull(h, {piece(dout, out, (size_t)m * n)});
 }
 
 int ccgp_corr_matrix(ccgp_handle* h, const double* X, int n, int d, const double* theta,
@@ -550,15 +647,10 @@ static int rinv_terms(ccgp_handle* h, const double* R_inv, const double* y, int 
   double* dmf = c.take<double>(n);
   double* dcs = c.take<double>(n);
   double* dsc = c.take<double>(4);
-  CCGP_HIP(hipMemcpyAsync(dR, R_inv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  if (int prc = push(h, {piece(dR, R_inv, (size_t)n * n), piece(dy, y, n)})) return prc;
   hipLaunchKernelGGL(rinv_terms_kernel, dim3(1), dim3(256), 0, h->stream, dR, dy, n, beta, dmf, dcs, dsc);
   CCGP_LAUNCH_CHECK();
-  if (mean_factor) CCGP_HIP(hipMemcpyAsync(mean_factor, dmf, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-  if (colsum) CCGP_HIP(hipMemcpyAsync(colsum, dcs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(scal, dsc, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipStreamSynchronize(h->stream));
-  return CCGP_OK;
+  return pull(h, {piece(dmf, mean_factor, n), piece(dcs, colsum, n), piece(dsc, scal, 3)});
 }
 
 int ccgp_beta_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double* out_beta) {
@@ -608,17 +700,54 @@ int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, dou
   double* dv1 = c.take<double>(n);
   double* dmean = c.take<double>(m);
   double* dvar = c.take<double>(m);
-  CCGP_HIP(hipMemcpyAsync(dR, R_inv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dr, r, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dmf, mean_factor, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dv1, var_factor1, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  if (int prc = push(h, {piece(dR, R_inv, (size_t)n * n), piece(dr, r, (size_t)m * n), piece(dmf, mean_factor, n),
+                         piece(dv1, var_factor1, n)}))
+    return prc;
   hipLaunchKernelGGL(predict_factors_kernel, dim3(m), dim3(256), 0, h->stream, dr, m, n, beta, dmf,
                      dv1, var_factor2, dR, sigma2, dmean, dvar);
   CCGP_LAUNCH_CHECK();
-  CCGP_HIP(hipMemcpyAsync(out_mean, dmean, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(out_var, dvar, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipStreamSynchronize(h->stream));
-  return CCGP_OK;
+  return pull(h, {piece(dmean, out_mean, m), piece(dvar, out_var, m)});
+}
+
+int ccgp_predict_post(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d, int K,
+                      const double* params_row, double beta, const double* mean_factor,
+                      const double* var_factor1, double var_factor2, const double* R_inv, double sigma2,
+                      double* out_mean, double* out_var) {
+  if (!h || bad_shape(n, d, K) || m < 1 || !Xnew || !X || !params_row || !mean_factor || !var_factor1 || !R_inv ||
+      !out_mean || !out_var)
+    return fail(h, CCGP_EINVAL, "ccgp_predict_post: bad argument");
+  CCGP_HIP(hipSetDevice(h->device));
+  const int P = K + K * d;
+  size_t need = Carver::al(sizeof(double) * (size_t)n * d) + Carver::al(sizeof(double) * (size_t)m * d) +
+                Carver::al(sizeof(double) * P) + 2 * Carver::al(sizeof(double) * n) +
+                Carver::al(sizeof(double) * (size_t)n * n) + Carver::al(sizeof(double) * (size_t)m * n) +
+                2 * Carver::al(sizeof(double) * m);
+  int rc = ensure_stage(h, need);
+  if (rc) return rc;
+  Carver c(h->stage);
+  double* dX = c.take<double>((size_t)n * d);
+  double* dXn = c.take<double>((size_t)m * d);
+  double* dp = c.take<double>(P);
+  double* dmf = c.take<double>(n);
+  double* dv1 = c.take<double>(n);
+  double* dR = c.take<double>((size_t)n * n);
+  double* dr = c.take<double>((size_t)m * n);
+  double* dmean = c.take<double>(m);
+  double* dvar = c.take<double>(m);
+  if (int prc = push(h, {piece(dX, X, (size_t)n * d), piece(dXn, Xnew, (size_t)m * d), piece(dp, params_row, P),
+                         piece(dmf, mean_factor, n), piece(dv1, var_factor1, n), piece(dR, R_inv, (size_t)n * n)}))
+    return prc;
+  DrawView dv{dp, 1, K, d};
+  dv.fam = h->fam;
+  if (int frc = check_family(h, dv.fam, d, K)) return frc;
+  {
+    ScopedTimer t(h, CCGP_T_COV);   // r = Mixed.corr.vec(x_t, D.train, ...) (HX:665), exactly ccgp_mixed_corr_cross's kernel
+    launch_cov_dense(h->stream, dXn, m, dX, n, d, dv, 0, dr, m);
+  }
+  hipLaunchKernelGGL(predict_factors_kernel, dim3(m), dim3(256), 0, h->stream, dr, m, n, beta, dmf, dv1,
+                     var_factor2, dR, sigma2, dmean, dvar);
+  CCGP_LAUNCH_CHECK();
+  return pull(h, {piece(dmean, out_mean, m), piece(dvar, out_var, m)});
 }
 
 // ---- a8/a9/a12 -------------------------------------------------------------------------------
@@ -776,9 +905,7 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   double* dbeta = c.take<double>(B);
   int* dst = c.take<int>(B);
   double* dgp = c.take<double>((size_t)B * nch * P);
-  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)B * P, hipMemcpyHostToDevice, h->stream));
+  if (int prc = push(h, {piece(dX, X, (size_t)n * d), piece(dy, y, n), piece(dp, params, (size_t)B * P)})) return prc;
   DrawView dv{dp, B, K, d};
   dv.fam = h->fam;
   if (int frc = check_family(h, dv.fam, d, K)) return frc;
@@ -791,11 +918,9 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   }
   CCGP_LAUNCH_CHECK();
   std::vector<int> st(B);
-  if (out_loglik) CCGP_HIP(hipMemcpyAsync(out_loglik, dll, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
-  if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(out_grad, dg, sizeof(double) * (size_t)B * P, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (int prc = pull(h, {piece(dg, out_grad, (size_t)B * P), piece(dll, out_loglik, B), piece(dbeta, out_beta, B),
+                         piece(dst, st.data(), B)}))
+    return prc;
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
   return count_bad(st.data(), B);
 }
@@ -960,8 +1085,7 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
   double* dp = c.take<double>(P);
   double* dld = c.take<double>(B);
   int* dst = c.take<int>(B);
-  CCGP_HIP(hipMemcpyAsync(dXs, Xs, sizeof(double) * (size_t)B * n * d, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+  if (int prc = push(h, {piece(dXs, Xs, (size_t)B * n * d), piece(dp, params, P)})) return prc;
   DrawView dv{dp, 1, K, d};
   dv.fam = h->fam;
   if (int frc = check_family(h, dv.fam, d, K)) return frc;
@@ -971,9 +1095,7 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
   }
   CCGP_LAUNCH_CHECK();
   std::vector<int> st(B);
-  CCGP_HIP(hipMemcpyAsync(out_logdet, dld, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (int prc = pull(h, {piece(dld, out_logdet, B), piece(dst, st.data(), B)})) return prc;
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
   return count_bad(st.data(), B);
 }
@@ -1158,18 +1280,15 @@ int ccgp_predict_batch(ccgp_handle* h, const double* X, int n, int d, const doub
   double* dvar = c.take<double>((size_t)S * m);
   double* dbeta = c.take<double>(S);
   int* dst = c.take<int>(S);
-  CCGP_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dp, params, sizeof(double) * (size_t)S * P, hipMemcpyHostToDevice, h->stream));
-  CCGP_HIP(hipMemcpyAsync(dXt, Xtest, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice, h->stream));
+  if (int prc = push(h, {piece(dX, X, (size_t)n * d), piece(dy, y, n), piece(dp, params, (size_t)S * P),
+                         piece(dXt, Xtest, (size_t)m * d)}))
+    return prc;
   rc = ccgp_predict_batch_dev(h, dX, n, d, dy, K, dp, S, dXt, m, sigma2, dmean, dvar, dbeta, dst);
   if (rc) return rc;
   std::vector<int> st(S);
-  CCGP_HIP(hipMemcpyAsync(out_mean, dmean, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(out_var, dvar, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));
-  if (out_beta) CCGP_HIP(hipMemcpyAsync(out_beta, dbeta, sizeof(double) * S, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipMemcpyAsync(st.data(), dst, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost, h->stream));
-  CCGP_HIP(hipStreamSynchronize(h->stream));
+  if (int prc = pull(h, {piece(dmean, out_mean, (size_t)S * m), piece(dvar, out_var, (size_t)S * m),
+                         piece(dbeta, out_beta, S), piece(dst, st.data(), S)}))
+    return prc;
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)S);
   return count_bad(st.data(), S);
 }

@@ -57,6 +57,10 @@ struct KernelFamily {
 
 }  // namespace ccgp
 
+namespace ccgp {
+constexpr int kPullSlices = 4;
+}
+
 struct ccgp_handle {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -76,6 +80,8 @@ struct ccgp_handle {
   // pinned host buffer: inputs and results of the one-draw-per-call path (ccgp_logpost) cross PCIe in one copy each
   void* pin = nullptr;
   size_t pin_bytes = 0;
+  size_t pin_in = 0;     // bytes of `pin` holding the inputs of the call in flight (results land behind them)
+  hipEvent_t pull_ev[ccgp::kPullSlices] = {};   // one per slice of a large result on its way back (capi.hip: pull)
   std::string err;
   ccgp::KernelFamily fam;
   unsigned timing = 0;   // bit i set: launch groups with id i are bracketed by HIP events

@@ -172,13 +172,15 @@ class CombinedGP:
         v1 = pars[o + 1 + n: o + 1 + 2 * n]
         v2 = pars[o + 1 + 2 * n]
         R_Inv = pars[o + 2 + 2 * n: o + 2 + 2 * n + n * n].reshape(n, n, order="F")
+        # r = Mixed.corr.vec(x.new, ...) (HX:665) and the arithmetic of HX:667-670 in ONE device round trip
         if self.cfg["aniso"]:
-            r = self.Mixed_corr_vec(x_new, D_train, p, theta1, theta2, pars[3])
+            row = pack_aniso(p, theta1, theta2, pars[3])
         elif self.script == "ADV":
-            r = self.Mixed_corr_vec(x_new, D_train, p, theta1, theta1 * (1.0 + theta2))  # ADV:672 as written
+            row = pack_iso(p, theta1, theta1 * (1.0 + theta2), D_train.shape[1])           # ADV:672 as written
         else:
-            r = self.Mixed_corr_vec(x_new, D_train, p, theta1, theta2)
-        mean, var = self.h.predict_from_factors(r.reshape(1, -1), beta, mf, v1, v2, R_Inv, sigma2)
+            row = pack_iso(p, theta1, theta2, D_train.shape[1])
+        mean, var = self.h.predict_post(np.asarray(x_new, dtype=np.float64).reshape(1, -1), D_train, 2, row, beta, mf,
+                                        v1, v2, R_Inv, sigma2)
         return np.array([[mean[0], var[0]]])
 
     def cross_corr_matrix(self, D_old, D_new, theta):

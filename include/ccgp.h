@@ -222,6 +222,17 @@ int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, dou
                               double var_factor2, const double* R_inv, double sigma2,
                               double* out_mean, double* out_var);
 
+/* predict.post(x.new, D.train, pars, sigma2) HX:655-673 as the scripts call it -- once per (draw, test site),
+ * HX:688 -- in ONE device round trip: r = Mixed.corr.vec(x_t, D.train, ...) (HX:665, the kernel of
+ * ccgp_mixed_corr_cross) for the m rows of Xnew, then the arithmetic of HX:667-670 with the caller's cached
+ * terms (the frame row's beta, mean.factor, var.factor1, var.factor2, R.Inv: HX:659-663).  Same bits as
+ * ccgp_mixed_corr_cross followed by ccgp_predict_from_factors; X, x.new, the parameter row and the n^2 + 2n cached
+ * doubles cross PCIe in one pinned copy, (mean, var) come back in one. */
+int ccgp_predict_post(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d, int K,
+                      const double* params_row, double beta, const double* mean_factor,
+                      const double* var_factor1, double var_factor2, const double* R_inv, double sigma2,
+                      double* out_mean, double* out_var);
+
 /* ---- entropy criteria of the batch-sequential design script ---------------------------
  * Entropy(D, p, theta1, theta2) = -det(R.mixed(D))  (Batch Sequential ME Design.R:856-861) and
  * Augmented.Mixed.Entropy = -det(R.new - R.cross R.old^-1 R.cross') (same file :869-877), which by

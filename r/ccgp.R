@@ -11,11 +11,27 @@
 #
 # Everything that calls these functions (Metro, laplace via logpost.val, factors.frame,
 # prediction, compare.GP, choose.hyperpars' callers) keeps working unchanged.
+#
+# The prediction phase (compare.GP -> prediction -> apply(pars.frame, 1, predict.post): S x m calls per test set,
+# HX:686-725, GV:620-676) runs as ONE device call: compare.GP and prediction are WRAPPED (the script's own
+# definitions are kept and still do everything that is not the (draw x site) mean / variance table: rnorm, quantile,
+# the CGP / mlegp comparators, plots).  Options, set before source():
+#     ccgp.slim.frame <- TRUE      # default: logpost does not form / ship R.Inv, factors.frame's result is S x 7
+#                                  #   instead of S x (5 + 2n + n^2); FALSE: the frame exactly as the script builds it
+#     ccgp.adv.as.written <- FALSE # ADV only: TRUE keeps predict.post's theta1 * (1 + lambda) second scale (ADV:672)
+#                                  #   through the literal per-draw path instead of the training kernel (ADV:417)
+# Every index into a frame or a frame row is computed in r/ccgp_shim.c (executed by the test-suite), not here.
 # Not executable in this repository's build container (no R); see INTEGRATION.md.
 
 dyn.load(Sys.getenv("CCGP_R_SHIM", "ccgpR.so"))
 
 if (!exists("ccgp.script")) ccgp.script <- "HX"
+if (!exists("ccgp.slim.frame")) ccgp.slim.frame <- TRUE
+if (!exists("ccgp.adv.as.written")) ccgp.adv.as.written <- FALSE
+# how a draw's leading frame columns map to the parameter row (r/ccgp_shim.c: LAYOUT_*)
+.ccgp.layout <- switch(ccgp.script, ANI = 2L, D1 = 3L, D1F = 4L, 0L)
+.ccgp.layout.written <- if (ccgp.script == "ADV") 1L else .ccgp.layout       # predict.post as the script writes it
+.ccgp.env <- new.env()               # y.train of the fit in progress (factors / compare.GP put it there)
 .ccgp.aniso <- ccgp.script == "ANI"
 .ccgp.prior <- switch(ccgp.script, HX = 0L, ADV = 0L, GV = 1L, ISO = 2L, BSQ = 2L, ANI = 3L, D1 = 2L, D1F = 2L)
 
@@ -63,7 +79,7 @@ sigma2.MLE <- function(R.Inv, y.train, beta) .Call("ccgp_R_sigma2_mle", .ccgp.ma
 # logpost: HX / ADV pass the inverse-gamma hyperparameters, the other scripts do not
 .ccgp.logpost <- function(D.train, theta, y, sigma2, pars) {
   r <- .Call("ccgp_R_logpost", .ccgp.mat(D.train), as.double(theta), as.double(y), as.double(sigma2),
-             .ccgp.prior, pars)
+             .ccgp.prior, pars, as.integer(!ccgp.slim.frame))      # slim: R.Inv is the 1 x 1 placeholder 0
   out <- list(val = r$val, beta = r$beta, R.Inv = r$R.Inv)
   if (ccgp.script == "ADV") out$like <- exp(r$loglik)
   out
@@ -92,32 +108,73 @@ if (ccgp.script %in% c("HX", "ADV")) {
 }
 
 factors <- function(MCMC.data, n.train, y.train) {
+  assign("y.train", as.double(y.train), envir = .ccgp.env)
+  # slim frame: MCMC.data is (placeholder, beta); two placeholders keep factors.frame's t(apply(...)) an S x 2 block
+  if (length(MCMC.data) < n.train^2 + 1) return(c(0, 0))
   R.Inv <- matrix(as.numeric(MCMC.data[1:n.train^2]), nrow = n.train)
   .Call("ccgp_R_factors", R.Inv, as.numeric(MCMC.data[n.train^2 + 1]), as.double(y.train))
 }
 
-predict.post <- function(x.new, D.train, pars, sigma2) {
-  n <- dim(D.train)[1]
-  o <- if (.ccgp.aniso) 4 else 3
-  pars <- as.numeric(pars)
-  r <- if (.ccgp.aniso) Mixed.corr.vec(x.new, D.train, pars[1], pars[2], pars[3], pars[4])
-       else if (ccgp.script == "ADV") Mixed.corr.vec(x.new, D.train, pars[1], pars[2], pars[2] * (1 + pars[3]))
-       else Mixed.corr.vec(x.new, D.train, pars[1], pars[2], pars[3])
-  out <- .Call("ccgp_R_predict_from_factors", matrix(r, nrow = 1), pars[o + 1],
-               pars[(o + 2):(o + 1 + n)], pars[(o + 2 + n):(o + 1 + 2 * n)], pars[o + 2 + 2 * n],
-               matrix(pars[(o + 3 + 2 * n):(o + 2 + 2 * n + n^2)], nrow = n), as.double(sigma2))
+# one frame row -> cbind(mean, var); the row is parsed in C (ccgp_R_predict_post), one device round trip per call
+predict.post <- function(x.new, D.train, pars, sigma2, nu = 0) {
+  out <- .Call("ccgp_R_predict_post", as.double(x.new), .ccgp.mat(D.train), as.numeric(pars), as.double(sigma2),
+               .ccgp.layout.written, as.double(nu))
   colnames(out) <- c("mean", "var")
   out
 }
 
-# Batched replacement for the apply(pars.frame, 1, predict.post) inside prediction(): the
-# whole (draw x test point) mean / variance table in one device call.
-ccgp.prediction.table <- function(D.test, draws, D.train, sigma2, y.train) {
-  d <- ncol(D.train)
-  P <- t(apply(.ccgp.mat(draws), 1, function(r)
-    if (.ccgp.aniso) .ccgp.row(d, r[1], r[2], r[3], r[4]) else .ccgp.row(d, r[1], r[2], r[3])))
-  r <- .Call("ccgp_R_predict_batch", .ccgp.mat(D.train), as.double(y.train), 2L, P,
-             .ccgp.mat(D.test), as.double(sigma2))
+# ---- the prediction phase as one device call -----------------------------------------------------------------
+# arguments of a call, matched to the formals of the script's own definition (the argument lists differ per script:
+# HX:686 prediction(x.new, alpha, pars.frame, D.train, sigma2), ANI:637 adds code, D1:825 adds nu, ...)
+.ccgp.bind <- function(f, ...) as.list(match.call(f, as.call(c(list(as.name("f")), list(...)))))[-1]
+.ccgp.nu <- function(a) if (is.null(a$nu)) 0 else as.double(a$nu)
+
+if (exists("compare.GP") && !exists(".ccgp.ref.compare.GP")) .ccgp.ref.compare.GP <- compare.GP
+if (exists("prediction") && !exists(".ccgp.ref.prediction")) .ccgp.ref.prediction <- prediction
+
+if (exists(".ccgp.ref.compare.GP")) {
+  # the whole (draw x test site) table once, kept on the C side while the script's compare.GP walks over D.test
+  compare.GP <- function(...) {
+    a <- .ccgp.bind(.ccgp.ref.compare.GP, ...)
+    D.new <- if (is.null(a$D.test)) a$D.new else a$D.test
+    assign("y.train", as.double(a$y.train), envir = .ccgp.env)
+    if (!(ccgp.script == "ADV" && ccgp.adv.as.written)) {
+      .Call("ccgp_R_table_cache", a$params, .ccgp.mat(a$D.train), .ccgp.mat(D.new), as.double(a$sigma2),
+            as.double(a$y.train), .ccgp.layout, .ccgp.nu(a))
+      on.exit(.Call("ccgp_R_table_clear"))
+    }
+    .ccgp.ref.compare.GP(...)
+  }
+}
+
+if (exists(".ccgp.ref.prediction")) {
+  # the script's own prediction() with its apply(pars.frame, 1, predict.post, ...) answered from the table: the
+  # 2 x S block (rows mean, var) that apply would have returned; everything after that line (rnorm, quantile, ...)
+  # is the script's code, untouched
+  prediction <- function(...) {
+    a <- .ccgp.bind(.ccgp.ref.prediction, ...)
+    S <- nrow(a$pars.frame)
+    tab <- .Call("ccgp_R_table_lookup", as.double(a$x.new), S)
+    if (is.null(tab) && !(ccgp.script == "ADV" && ccgp.adv.as.written) &&
+        ncol(a$pars.frame) < nrow(a$D.train)^2 && exists("y.train", envir = .ccgp.env) &&
+        length(get("y.train", envir = .ccgp.env)) == nrow(a$D.train)) {
+      # outside compare.GP with a slim frame: the table of this one site
+      r <- .Call("ccgp_R_prediction_table", a$pars.frame, .ccgp.mat(a$D.train), matrix(as.double(a$x.new), nrow = 1),
+                 as.double(a$sigma2), get("y.train", envir = .ccgp.env), .ccgp.layout, .ccgp.nu(a))
+      tab <- rbind(as.vector(r[[1]]), as.vector(r[[2]]))
+    }
+    if (is.null(tab)) return(.ccgp.ref.prediction(...))          # full frame, unknown site: the literal path
+    f <- .ccgp.ref.prediction
+    environment(f) <- list2env(list(apply = function(X, MARGIN, FUN, ...) tab), parent = environment(.ccgp.ref.prediction))
+    f(...)
+  }
+}
+
+# The (draw x site) tables directly: draws = a factors.frame() result or any matrix / data frame whose leading
+# columns are p, theta1, theta2[, lambda]
+ccgp.prediction.table <- function(D.test, draws, D.train, sigma2, y.train, nu = 0) {
+  r <- .Call("ccgp_R_prediction_table", draws, .ccgp.mat(D.train), .ccgp.mat(D.test), as.double(sigma2),
+             as.double(y.train), .ccgp.layout, as.double(nu))
   list(mean = r[[1]], var = r[[2]], beta = r[[3]])
 }
 
@@ -155,16 +212,7 @@ if (ccgp.script == "D1") {
                                      .ccgp.mat(D.train), 2L, c(p, 1 - p, theta1, theta2))))
   logpost <- function(D.train, theta, y, sigma2, nu)                                      # D1:609-641
     .ccgp.matern(nu, .ccgp.logpost(D.train, theta, y, sigma2, NULL))
-  predict.post <- function(x.new, D.train, pars, sigma2, nu) {                            # D1:794-812
-    n <- dim(D.train)[1]
-    pars <- as.numeric(pars)
-    r <- Mixed.corr.vec(x.new, D.train, pars[1], pars[2], pars[3], nu = nu)
-    out <- .Call("ccgp_R_predict_from_factors", matrix(r, nrow = 1), pars[4], pars[5:(4 + n)],
-                 pars[(5 + n):(4 + 2 * n)], pars[5 + 2 * n],
-                 matrix(pars[(6 + 2 * n):(5 + 2 * n + n^2)], nrow = n), as.double(sigma2))
-    colnames(out) <- c("mean", "var")
-    out
-  }
+  # predict.post (D1:794-812), prediction and compare.GP: the generic definitions above (layout 3, nu passed on)
 }
 
 
@@ -189,21 +237,6 @@ if (ccgp.script == "D1F") {
                                   c(p, 1 - p, theta1, theta2))))
   logpost <- function(D.train, theta, y, sigma2, nu)                                      # D1F:576-602
     .ccgp.two(nu, .ccgp.logpost(D.train, theta, y, sigma2, NULL))
-  predict.post <- function(x.new, D.train, pars, sigma2, nu) {                            # D1F:737-754
-    n <- dim(D.train)[1]
-    pars <- as.numeric(pars)
-    r <- corr.vec.combined(x.new, D.train, pars[1], pars[2], pars[3], nu)
-    out <- .Call("ccgp_R_predict_from_factors", matrix(r, nrow = 1), pars[4], pars[5:(4 + n)],
-                 pars[(5 + n):(4 + 2 * n)], pars[5 + 2 * n],
-                 matrix(pars[(6 + 2 * n):(5 + 2 * n + n^2)], nrow = n), as.double(sigma2))
-    colnames(out) <- c("mean", "var")
-    out
-  }
-  # batched (draw x site) tables with this family: the device uses the same un-normalised r
-  ccgp.prediction.table <- function(D.test, draws, D.train, sigma2, y.train, nu) {
-    P <- t(apply(.ccgp.mat(draws), 1, function(r) c(r[1], 1 - r[1], r[2], r[3])))
-    r <- .ccgp.two(nu, .Call("ccgp_R_predict_batch", .ccgp.mat(D.train), as.double(y.train), 2L, P,
-                             .ccgp.mat(D.test), as.double(sigma2)))
-    list(mean = r[[1]], var = r[[2]], beta = r[[3]])
-  }
+  # predict.post (D1F:737-754, with corr.vec.combined's un-normalised r), prediction, compare.GP and
+  # ccgp.prediction.table: the generic definitions above (layout 4, nu passed on)
 }

@@ -125,14 +125,17 @@ SEXP ccgp_R_mixed_corr_cross(SEXP Xnew, SEXP X, SEXP K, SEXP params) {
   return out;
 }
 
-/* logpost -> list(val, beta, R.Inv, loglik) -- HX:441-466 and its per-script variants */
-SEXP ccgp_R_logpost(SEXP X, SEXP theta_t, SEXP y, SEXP sigma2, SEXP prior_id, SEXP prior_pars) {
+/* logpost -> list(val, beta, R.Inv, loglik) -- HX:441-466 and its per-script variants.  want_rinv = FALSE (the slim
+ * frame of r/ccgp.R: the prediction phase goes through ccgp_R_prediction_table and never reads R.Inv): solve(R) is
+ * neither formed nor shipped, R.Inv is the 1 x 1 placeholder 0 that Metro stores per accepted draw (HX:520) */
+SEXP ccgp_R_logpost(SEXP X, SEXP theta_t, SEXP y, SEXP sigma2, SEXP prior_id, SEXP prior_pars, SEXP want_rinv) {
   int n = Rf_nrows(X), d = Rf_ncols(X), status = 0;
+  const int want = Rf_asInteger(want_rinv) != 0;
   double val = NA_REAL, beta = NA_REAL, ll = NA_REAL;
-  SEXP Rinv = PROTECT(Rf_allocMatrix(REALSXP, n, n));
+  SEXP Rinv = PROTECT(want ? Rf_allocMatrix(REALSXP, n, n) : Rf_ScalarReal(0.0));
   const double* pp = Rf_isNull(prior_pars) ? NULL : REAL(prior_pars);
   int rc = ccgp_logpost(handle(), REAL(X), n, d, REAL(y), Rf_asReal(sigma2), Rf_asInteger(prior_id),
-                        REAL(theta_t), pp, &val, &beta, &ll, REAL(Rinv), &status);
+                        REAL(theta_t), pp, &val, &beta, &ll, want ? REAL(Rinv) : NULL, &status);
   warn_rc(rc);
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 4));
   SEXP names = PROTECT(Rf_allocVector(STRSXP, 4));
@@ -242,6 +245,242 @@ SEXP ccgp_R_predict_from_factors(SEXP r, SEXP beta, SEXP mean_factor, SEXP var_f
   return out;
 }
 
+/* ---- the prediction phase of the unchanged scripts -------------------------------------------------------------
+ * prediction() runs apply(pars.frame, 1, predict.post, x.new = ...) for every test site (HX:688, GV:622) and
+ * compare.GP runs prediction() for every row of D.test (HX:719, GV:671): S x m calls of predict.post, each re-parsing
+ * an (5 + 2n + n^2)-wide frame row.  The stubs below take the frame factors.frame() returned (HX:625-644) -- a data
+ * frame (list of columns) or a numeric matrix, columns p, theta1, theta2[, lambda] first -- and produce the whole
+ * S x m table in ONE ccgp_predict_batch call; everything that indexes a frame or a frame row lives here, in C that
+ * the test-suite executes, not in r/ccgp.R.
+ *
+ * layout: how a draw's leading columns map to the C-ABI parameter row
+ *   0  (p, theta1, theta2), isotropic in d dimensions              HX:408-415, GV, ISO, BSQ; ADV's training kernel ADV:414-421
+ *   1  ADV's predict.post AS WRITTEN: second scale theta1 (1 + pars[3])     ADV:672 (literal path only)
+ *   2  (p, theta1, theta2, lambda), anisotropic, d = 2              ANI:399-406
+ *   3  1-D Matern(nu) pair                                          D1:575-584
+ *   4  1-D Matern(nu) + cubic spline                                D1F:453-462                              */
+enum { LAYOUT_ISO = 0, LAYOUT_ADV_WRITTEN = 1, LAYOUT_ANI = 2, LAYOUT_D1 = 3, LAYOUT_D1F = 4 };
+
+static int layout_ok(int layout, int d) {
+  if (layout < LAYOUT_ISO || layout > LAYOUT_D1F) return 0;
+  if (layout == LAYOUT_ANI && d != 2) return 0;
+  if ((layout == LAYOUT_D1 || layout == LAYOUT_D1F) && d != 1) return 0;
+  return 1;
+}
+
+/* one draw -> (w_1, w_2, theta_1k.., theta_2k..) written with stride ld (a column-major B x P matrix has ld = B) */
+static void pack_draw(int layout, int d, double p, double t1, double t2, double lam, double* row, R_xlen_t ld) {
+  row[0] = p;
+  row[ld] = 1.0 - p;
+  if (layout == LAYOUT_ANI) {
+    row[2 * ld] = t1;
+    row[3 * ld] = t2;
+    row[4 * ld] = (1.0 + lam) * t1;
+    row[5 * ld] = (1.0 + lam) * t2;
+    return;
+  }
+  const double second = layout == LAYOUT_ADV_WRITTEN ? t1 * (1.0 + t2) : t2;
+  for (int k = 0; k < d; ++k) {
+    row[(2 + k) * ld] = t1;
+    row[(2 + d + k) * ld] = second;
+  }
+}
+
+/* a frame: data.frame (VECSXP of equally long numeric columns) or numeric matrix */
+static int frame_rows(SEXP f) {
+  if (TYPEOF(f) == VECSXP) return Rf_length(f) > 0 ? Rf_length(VECTOR_ELT(f, 0)) : 0;
+  return Rf_nrows(f);
+}
+static int frame_cols(SEXP f) { return TYPEOF(f) == VECSXP ? Rf_length(f) : Rf_ncols(f); }
+static double frame_get(SEXP f, int s, int j, int S) {
+  SEXP col = f;
+  R_xlen_t at = (R_xlen_t)s + (R_xlen_t)j * S;
+  if (TYPEOF(f) == VECSXP) { col = VECTOR_ELT(f, j); at = s; }
+  if (TYPEOF(col) == REALSXP) return REAL(col)[at];
+  if (TYPEOF(col) == INTSXP) return INTEGER(col)[at] == NA_INTEGER ? NA_REAL : (double)INTEGER(col)[at];
+  return NA_REAL;
+}
+
+/* the Matern / spline families of the 1-D scripts for the duration of one batched call */
+static int family_of(int layout) { return layout == LAYOUT_D1 ? 1 : layout == LAYOUT_D1F ? 2 : 0; }
+static int enter_family(int layout, double nu) {
+  const int fam = family_of(layout);
+  if (!fam) return 0;
+  int rc = ccgp_set_kernel(handle(), fam, nu);
+  if (rc == 0 && multi()) rc = ccgp_multi_set_kernel(g_multi, fam, nu);
+  return rc;
+}
+static void leave_family(int layout) {
+  if (!family_of(layout)) return;
+  ccgp_set_kernel(handle(), 0, 0.0);
+  if (multi()) ccgp_multi_set_kernel(g_multi, 0, 0.0);
+}
+
+/* scratch for the S x P parameter matrix of a frame; the caller keeps it PROTECTed until it returns */
+static SEXP alloc_params(SEXP frame, SEXP Dtrain) {
+  const int S = frame_rows(frame), d = Rf_ncols(Dtrain);
+  return Rf_allocMatrix(REALSXP, S > 0 ? S : 1, 2 + 2 * (d > 0 ? d : 1));
+}
+
+/* mean / var: S x m column-major, beta: S (may be NULL).  Returns the library's code (< 0: nothing usable). */
+static int table_into(SEXP frame, SEXP Dtrain, SEXP Dtest, SEXP sigma2, SEXP ytrain, int layout, double nu,
+                      SEXP params, double* mean, double* var, double* beta) {
+  const int n = Rf_nrows(Dtrain), d = Rf_ncols(Dtrain), m = Rf_nrows(Dtest), S = frame_rows(frame);
+  const int need = layout == LAYOUT_ANI ? 4 : 3;
+  if (!layout_ok(layout, d) || layout == LAYOUT_ADV_WRITTEN || S < 1 || m < 1 || frame_cols(frame) < need ||
+      Rf_ncols(Dtest) != d || Rf_length(ytrain) != n) {
+    Rf_warning("libccgp: prediction table: frame / design shapes do not fit layout %d", layout);
+    return CCGP_EINVAL;
+  }
+  for (int s = 0; s < S; ++s)
+    pack_draw(layout, d, frame_get(frame, s, 0, S), frame_get(frame, s, 1, S), frame_get(frame, s, 2, S),
+              need == 4 ? frame_get(frame, s, 3, S) : 0.0, REAL(params) + s, S);
+  int rc = enter_family(layout, nu);
+  if (rc < 0) {
+    warn_rc(rc);
+  } else if (multi()) {   /* sharded over the posterior draws */
+    rc = ccgp_multi_predict_batch(g_multi, REAL(Dtrain), n, d, REAL(ytrain), 2, REAL(params), S, REAL(Dtest), m,
+                                  Rf_asReal(sigma2), mean, var, beta, NULL);
+    warn_rc_multi(rc);
+  } else {
+    rc = ccgp_predict_batch(handle(), REAL(Dtrain), n, d, REAL(ytrain), 2, REAL(params), S, REAL(Dtest), m,
+                            Rf_asReal(sigma2), mean, var, beta, NULL);
+    warn_rc(rc);
+  }
+  leave_family(layout);
+  if (rc >= 0) {   /* a draw whose factorisation failed: NA, as the reference's R.Inv <- NA propagates (HX:454-455) */
+    for (R_xlen_t i = 0; i < (R_xlen_t)S * m; ++i)
+      if (ISNAN(mean[i]) || ISNAN(var[i])) { mean[i] = NA_REAL; var[i] = NA_REAL; }
+  }
+  return rc;
+}
+
+/* the (draw x test site) tables of a whole frame -> list(mean S x m, var S x m, beta S) */
+SEXP ccgp_R_prediction_table(SEXP frame, SEXP Dtrain, SEXP Dtest, SEXP sigma2, SEXP ytrain, SEXP layout, SEXP nu) {
+  const int S = frame_rows(frame) > 0 ? frame_rows(frame) : 1, m = Rf_nrows(Dtest) > 0 ? Rf_nrows(Dtest) : 1;
+  SEXP mean = PROTECT(Rf_allocMatrix(REALSXP, S, m));
+  SEXP var = PROTECT(Rf_allocMatrix(REALSXP, S, m));
+  SEXP beta = PROTECT(Rf_allocVector(REALSXP, S));
+  SEXP params = PROTECT(alloc_params(frame, Dtrain));
+  int rc = table_into(frame, Dtrain, Dtest, sigma2, ytrain, Rf_asInteger(layout), Rf_asReal(nu), params, REAL(mean),
+                      REAL(var), REAL(beta));
+  if (rc < 0) { fill_na(REAL(mean), (R_xlen_t)S * m); fill_na(REAL(var), (R_xlen_t)S * m); fill_na(REAL(beta), S); }
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 3));
+  SET_VECTOR_ELT(out, 0, mean);
+  SET_VECTOR_ELT(out, 1, var);
+  SET_VECTOR_ELT(out, 2, beta);
+  UNPROTECT(5);
+  return out;
+}
+
+/* compare.GP's table, computed once and kept on the C side while the script's own compare.GP walks over the rows of
+ * D.test (apply_pb(D.test, 1, prediction, ...), HX:719): ccgp_R_table_cache fills it, ccgp_R_table_lookup hands
+ * prediction() the 2 x S block apply(pars.frame, 1, predict.post, ...) would have produced for x.new (rows mean, var:
+ * HX:688 transposes it), ccgp_R_table_clear drops it (on.exit of the compare.GP wrapper). */
+static struct {
+  double *mean, *var, *Dtest;
+  int S, m, d, next;
+} g_tab = {NULL, NULL, NULL, 0, 0, 0, 0};
+
+static void table_drop(void) {
+  free(g_tab.mean); free(g_tab.var); free(g_tab.Dtest);
+  g_tab.mean = g_tab.var = g_tab.Dtest = NULL;
+  g_tab.S = g_tab.m = g_tab.d = g_tab.next = 0;
+}
+
+SEXP ccgp_R_table_clear(void) {
+  table_drop();
+  return R_NilValue;
+}
+
+/* -> number of draws cached (0: nothing cached, prediction() then takes the literal path) */
+SEXP ccgp_R_table_cache(SEXP frame, SEXP Dtrain, SEXP Dtest, SEXP sigma2, SEXP ytrain, SEXP layout, SEXP nu) {
+  table_drop();
+  const int S = frame_rows(frame), m = Rf_nrows(Dtest), d = Rf_ncols(Dtest);
+  if (S < 1 || m < 1 || d < 1) return Rf_ScalarInteger(0);
+  g_tab.mean = (double*)malloc(sizeof(double) * (size_t)S * m);
+  g_tab.var = (double*)malloc(sizeof(double) * (size_t)S * m);
+  g_tab.Dtest = (double*)malloc(sizeof(double) * (size_t)m * d);
+  if (!g_tab.mean || !g_tab.var || !g_tab.Dtest) {
+    table_drop();
+    Rf_warning("libccgp: no memory for a %d x %d prediction table", S, m);
+    return Rf_ScalarInteger(0);
+  }
+  SEXP params = PROTECT(alloc_params(frame, Dtrain));
+  const int rc = table_into(frame, Dtrain, Dtest, sigma2, ytrain, Rf_asInteger(layout), Rf_asReal(nu), params,
+                            g_tab.mean, g_tab.var, NULL);
+  if (rc < 0) {
+    table_drop();
+  } else {
+    memcpy(g_tab.Dtest, REAL(Dtest), sizeof(double) * (size_t)m * d);
+    g_tab.S = S; g_tab.m = m; g_tab.d = d; g_tab.next = 0;
+  }
+  SEXP out = Rf_ScalarInteger(rc < 0 ? 0 : S);
+  UNPROTECT(1);
+  return out;
+}
+
+/* x.new (d numbers) must be a row of the cached D.test, compared exactly; the search starts behind the previous hit
+ * (apply walks the rows in order) and wraps.  NULL: no table, another frame size, or an unknown site. */
+SEXP ccgp_R_table_lookup(SEXP xnew, SEXP S_) {
+  if (!g_tab.mean || Rf_length(xnew) != g_tab.d || Rf_asInteger(S_) != g_tab.S) return R_NilValue;
+  const double* x = REAL(xnew);
+  int hit = -1;
+  for (int q = 0; q < g_tab.m && hit < 0; ++q) {
+    const int t = (g_tab.next + q) % g_tab.m;
+    int same = 1;
+    for (int k = 0; k < g_tab.d && same; ++k) same = g_tab.Dtest[t + (size_t)k * g_tab.m] == x[k];
+    if (same) hit = t;
+  }
+  if (hit < 0) return R_NilValue;
+  g_tab.next = (hit + 1) % g_tab.m;
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, 2, g_tab.S));
+  for (int s = 0; s < g_tab.S; ++s) {
+    REAL(out)[2 * (size_t)s] = g_tab.mean[s + (size_t)hit * g_tab.S];
+    REAL(out)[2 * (size_t)s + 1] = g_tab.var[s + (size_t)hit * g_tab.S];
+  }
+  UNPROTECT(1);
+  return out;
+}
+
+/* predict.post(x.new, D.train, pars, sigma2[, nu]) -- HX:655-673, ANI:604-623, ADV:660-678, D1:794-812, D1F:737-754:
+ * pars is ONE frame row (p, theta1, theta2[, lambda], beta, mean.factor[n], var.factor1[n], var.factor2, R.Inv[n^2]);
+ * one device round trip (ccgp_predict_post) -> cbind(mean, var), one row per site in x.new (a d-vector or an m x d
+ * matrix).  A slim frame row (no cached terms) cannot be served here: warning + NA. */
+SEXP ccgp_R_predict_post(SEXP xnew, SEXP Dtrain, SEXP pars, SEXP sigma2, SEXP layout_, SEXP nu) {
+  const int n = Rf_nrows(Dtrain), d = Rf_ncols(Dtrain), layout = Rf_asInteger(layout_);
+  const int has_dim = !Rf_isNull(Rf_getAttrib(xnew, R_DimSymbol));
+  const int m = has_dim ? Rf_nrows(xnew) : 1;
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, m > 0 ? m : 1, 2)); /* cbind(mean, var) */
+  const int o = layout == LAYOUT_ANI ? 4 : 3;   /* pars[o + 1] is beta (1-based), HX:659 / ANI:611 */
+  const R_xlen_t want = (R_xlen_t)o + 2 + 2 * (R_xlen_t)n + (R_xlen_t)n * n;
+  int rc = CCGP_EINVAL;
+  if (!layout_ok(layout, d) || m < 1 || Rf_xlength(xnew) != (R_xlen_t)m * d) {
+    Rf_warning("libccgp: predict.post: x.new / D.train do not fit layout %d", layout);
+  } else if (Rf_xlength(pars) < want) {
+    Rf_warning("libccgp: predict.post needs a full factors.frame row (%ld numbers for n = %d), got %ld: slim frames "
+               "(ccgp.slim.frame) are served by prediction() / compare.GP / ccgp.prediction.table",
+               (long)want, n, (long)Rf_xlength(pars));
+  } else {
+    const double* q = REAL(pars);
+    double row[2 + 2 * 64];
+    if (d > 64) {
+      Rf_warning("libccgp: predict.post: more than 64 input dimensions");
+    } else {
+      pack_draw(layout, d, q[0], q[1], q[2], o == 4 ? q[3] : 0.0, row, 1);
+      rc = enter_family(layout, Rf_asReal(nu));
+      if (rc >= 0)
+        rc = ccgp_predict_post(handle(), REAL(xnew), m, REAL(Dtrain), n, d, 2, row, q[o], q + o + 1, q + o + 1 + n,
+                               q[o + 1 + 2 * n], q + o + 2 + 2 * n, Rf_asReal(sigma2), REAL(out), REAL(out) + m);
+      warn_rc(rc);
+      leave_family(layout);
+    }
+  }
+  if (rc < 0) fill_na(REAL(out), 2 * (R_xlen_t)(m > 0 ? m : 1));
+  UNPROTECT(1);
+  return out;
+}
+
 /* factors(MCMC.data, n.train, y.train) -- HX:604-613 */
 SEXP ccgp_R_factors(SEXP R_inv, SEXP beta, SEXP y) {
   int n = Rf_length(y);
@@ -301,11 +540,16 @@ static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_corr_cross", (DL_FUNC)&ccgp_R_corr_cross, 3},
     {"ccgp_R_mixed_corr_matrix", (DL_FUNC)&ccgp_R_mixed_corr_matrix, 3},
     {"ccgp_R_mixed_corr_cross", (DL_FUNC)&ccgp_R_mixed_corr_cross, 4},
-    {"ccgp_R_logpost", (DL_FUNC)&ccgp_R_logpost, 6},
+    {"ccgp_R_logpost", (DL_FUNC)&ccgp_R_logpost, 7},
     {"ccgp_R_loglik_batch", (DL_FUNC)&ccgp_R_loglik_batch, 7},
     {"ccgp_R_grid_marginal", (DL_FUNC)&ccgp_R_grid_marginal, 8},
     {"ccgp_R_predict_batch", (DL_FUNC)&ccgp_R_predict_batch, 6},
     {"ccgp_R_predict_from_factors", (DL_FUNC)&ccgp_R_predict_from_factors, 7},
+    {"ccgp_R_prediction_table", (DL_FUNC)&ccgp_R_prediction_table, 7},
+    {"ccgp_R_table_cache", (DL_FUNC)&ccgp_R_table_cache, 7},
+    {"ccgp_R_table_lookup", (DL_FUNC)&ccgp_R_table_lookup, 2},
+    {"ccgp_R_table_clear", (DL_FUNC)&ccgp_R_table_clear, 0},
+    {"ccgp_R_predict_post", (DL_FUNC)&ccgp_R_predict_post, 6},
     {"ccgp_R_factors", (DL_FUNC)&ccgp_R_factors, 3},
     {"ccgp_R_beta_mle", (DL_FUNC)&ccgp_R_beta_mle, 2},
     {"ccgp_R_sigma2_mle", (DL_FUNC)&ccgp_R_sigma2_mle, 3},
@@ -324,4 +568,5 @@ void R_unload_ccgpR(DllInfo* dll) {
   if (g_handle) { ccgp_destroy(g_handle); g_handle = NULL; }
   if (g_multi) { ccgp_multi_destroy(g_multi); g_multi = NULL; }
   g_multi_tried = 0;   /* CCGP_DEVICES is read again after a reload */
+  table_drop();
 }

@@ -172,6 +172,15 @@ int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, dou
   for (int t = 0; t < m; ++t) { out_mean[t] = s + t; out_var[t] = s - t; }
   return CCGP_OK;
 }
+int ccgp_predict_post(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d, int K, const double* params_row,
+                      double beta, const double* mean_factor, const double* var_factor1, double var_factor2, const double* R_inv,
+                      double sigma2, double* out_mean, double* out_var) {
+  if (!h || !Xnew || !X || !params_row || !mean_factor || !var_factor1 || !R_inv || !out_mean || !out_var || K < 1 || K > 8) return CCGP_EINVAL;
+  const double s = touch(Xnew, (size_t)m * d) + touch(X, (size_t)n * d) + touch(params_row, K + K * d) + touch(mean_factor, n) +
+                   touch(var_factor1, n) + touch(R_inv, (size_t)n * n) + beta + var_factor2 + sigma2 + h->family;
+  for (int t = 0; t < m; ++t) { out_mean[t] = s + t; out_var[t] = s - t; }
+  return CCGP_OK;
+}
 int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2, int prior_id, const double* theta_t,
                  const double* prior_pars, double* out_val, double* out_beta, double* out_loglik, double* out_Rinv, int* status) {
   if (!h || !X || !y || !theta_t || !out_val) return CCGP_EINVAL;

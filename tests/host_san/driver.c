@@ -22,6 +22,10 @@ SEXP rmock_dot_call(const char* name, int nargs, SEXP* a);
 SEXP rmock_real(const double* v, R_xlen_t n, int nrow, int ncol);
 SEXP rmock_int(const int* v, R_xlen_t n);
 SEXP rmock_nil(void);
+SEXP rmock_list(R_xlen_t n);
+void rmock_list_set(SEXP l, R_xlen_t i, SEXP v);
+void rmock_list_names(SEXP l, const char** names, int n_names);
+int rmock_typeof(SEXP x);
 SEXP rmock_elt(SEXP x, long i);
 void* rmock_data(SEXP x);
 long rmock_length(SEXP x);
@@ -158,7 +162,7 @@ static void shim_scenarios(void) {
   double* y = filled(N, 2.0);
   double* th = filled(D, 0.3);
   const int Kk = K, zero = 0, one_i = 1;
-  CHECK(rmock_load() >= 15, "registration");
+  CHECK(rmock_load() >= 20, "registration");
   rmock_reset();
   SEXP a[8];
   /* single device: every routine once */
@@ -180,12 +184,15 @@ static void shim_scenarios(void) {
   call("ccgp_R_mixed_corr_cross", 4, a);
   double tt[3] = {0.1, 0.2, 0.3}, s2 = 2.5, pp[4] = {7, 3, 3, 28};
   a[0] = rmock_real(X, N * D, N, D); a[1] = rmock_real(tt, 3, -1, 0); a[2] = rmock_real(y, N, -1, 0); a[3] = rmock_real(&s2, 1, -1, 0);
-  a[4] = rmock_int(&zero, 1); a[5] = rmock_real(pp, 4, -1, 0);
-  r = call("ccgp_R_logpost", 6, a);
+  a[4] = rmock_int(&zero, 1); a[5] = rmock_real(pp, 4, -1, 0); a[6] = rmock_int(&one_i, 1);
+  r = call("ccgp_R_logpost", 7, a);
   CHECK(r && rmock_length(r) == 4 && rmock_length(rmock_elt(r, 2)) == N * N, "logpost list");
+  a[6] = rmock_int(&zero, 1);                                        /* slim frame: R.Inv is the 1 x 1 placeholder */
+  r = call("ccgp_R_logpost", 7, a);
+  CHECK(r && rmock_length(rmock_elt(r, 2)) == 1 && reals(rmock_elt(r, 2))[0] == 0.0, "logpost without R.Inv");
   tt[0] = -800.0;
-  a[1] = rmock_real(tt, 3, -1, 0); a[4] = rmock_int(&one_i, 1); a[5] = rmock_nil();
-  r = call("ccgp_R_logpost", 6, a);
+  a[1] = rmock_real(tt, 3, -1, 0); a[4] = rmock_int(&one_i, 1); a[5] = rmock_nil(); a[6] = rmock_int(&one_i, 1);
+  r = call("ccgp_R_logpost", 7, a);
   CHECK(r && rmock_is_na_real(reals(rmock_elt(r, 0))[0]) && rmock_length(rmock_elt(r, 2)) == 1, "failed logpost -> NA, R.Inv <- NA");
   const int B = 11;
   double* params = filled((size_t)B * P, 0.5);
@@ -214,6 +221,65 @@ static void shim_scenarios(void) {
   SEXP single_pred = call("ccgp_R_predict_batch", 6, a);
   double* mean_keep = (double*)malloc(sizeof(double) * B * 4);
   memcpy(mean_keep, reals(rmock_elt(single_pred, 0)), sizeof(double) * B * 4);
+  /* the prediction phase: a frame (data.frame = list of columns, or a matrix) -> one table; cache / lookup / clear */
+  const int S = 5, mt = 4;
+  double* fr = filled((size_t)S * 4, 0.2);                           /* p, theta1, theta2, beta columns */
+  for (int i = 0; i < S; ++i) fr[i] = 0.1 + 0.15 * i;
+  SEXP frame = rmock_list(4);
+  for (int j = 0; j < 4; ++j) rmock_list_set(frame, j, rmock_real(fr + (size_t)j * S, S, -1, 0));
+  const char* fn[4] = {"p", "theta1", "theta2", "beta"};
+  rmock_list_names(frame, fn, 4);
+  double zero_d = 0.0;
+  a[0] = frame; a[1] = rmock_real(X, N * D, N, D); a[2] = rmock_real(Xt, mt * D, mt, D); a[3] = rmock_real(&s2, 1, -1, 0);
+  a[4] = rmock_real(y, N, -1, 0); a[5] = rmock_int(&zero, 1); a[6] = rmock_real(&zero_d, 1, -1, 0);
+  SEXP tab = call("ccgp_R_prediction_table", 7, a);
+  CHECK(tab && rmock_length(tab) == 3 && rmock_length(rmock_elt(tab, 0)) == S * mt && rmock_length(rmock_elt(tab, 2)) == S, "table shapes");
+  a[0] = rmock_real(fr, S * 4, S, 4);                               /* the same draws as a numeric matrix */
+  SEXP tab2 = call("ccgp_R_prediction_table", 7, a);
+  CHECK(tab2 && same(reals(rmock_elt(tab, 0)), reals(rmock_elt(tab2, 0)), (size_t)S * mt) &&
+            same(reals(rmock_elt(tab, 1)), reals(rmock_elt(tab2, 1)), (size_t)S * mt), "data frame == matrix");
+  a[0] = frame;
+  r = call("ccgp_R_table_cache", 7, a);
+  CHECK(r && ((int*)rmock_data(r))[0] == S, "table_cache returns the number of draws");
+  for (int pass = 0; pass < 2; ++pass)                               /* in order, then again (wrap-around) */
+    for (int t = 0; t < mt; ++t) {
+      double xr[D];
+      for (int k = 0; k < D; ++k) xr[k] = Xt[t + (size_t)k * mt];
+      SEXP b[2] = {rmock_real(xr, D, -1, 0), rmock_int(&S, 1)};
+      r = call("ccgp_R_table_lookup", 2, b);
+      int ok = r && rmock_length(r) == 2 * S;
+      for (int q = 0; ok && q < S; ++q)
+        ok = reals(r)[2 * q] == reals(rmock_elt(tab, 0))[q + (size_t)t * S] && reals(r)[2 * q + 1] == reals(rmock_elt(tab, 1))[q + (size_t)t * S];
+      CHECK(ok, "lookup of test site %d (pass %d)", t, pass);
+    }
+  {
+    double far[D] = {9.0, 9.0, 9.0};
+    const int S1 = S + 1;
+    SEXP b[2] = {rmock_real(far, D, -1, 0), rmock_int(&S, 1)};
+    r = call("ccgp_R_table_lookup", 2, b);
+    CHECK(r && rmock_typeof(r) == 0, "unknown site -> NULL");
+    double xr[D];
+    for (int k = 0; k < D; ++k) xr[k] = Xt[(size_t)k * mt];
+    b[0] = rmock_real(xr, D, -1, 0); b[1] = rmock_int(&S1, 1);
+    r = call("ccgp_R_table_lookup", 2, b);
+    CHECK(r && rmock_typeof(r) == 0, "another frame size -> NULL");
+    call("ccgp_R_table_clear", 0, b);
+    b[1] = rmock_int(&S, 1);
+    r = call("ccgp_R_table_lookup", 2, b);
+    CHECK(r && rmock_typeof(r) == 0, "cleared -> NULL");
+  }
+  /* a frame too narrow for the layout (ANI needs 4 leading columns): warning + NA, never an error */
+  {
+    const int two = 2, w0 = rmock_n_warnings();
+    SEXP narrow = rmock_list(3);
+    for (int j = 0; j < 3; ++j) rmock_list_set(narrow, j, rmock_real(fr + (size_t)j * S, S, -1, 0));
+    double* X2 = filled((size_t)N * 2, 0.1);
+    double* Xt2 = filled((size_t)mt * 2, 0.6);
+    a[0] = narrow; a[1] = rmock_real(X2, N * 2, N, 2); a[2] = rmock_real(Xt2, mt * 2, mt, 2); a[5] = rmock_int(&two, 1);
+    r = call("ccgp_R_prediction_table", 7, a);
+    CHECK(r && rmock_is_na_real(reals(rmock_elt(r, 0))[0]) && rmock_n_warnings() == w0 + 1, "narrow frame -> warning + NA");
+    free(X2); free(Xt2);
+  }
   /* literal helpers */
   double* Rinv = filled((size_t)N * N, 0.01);
   double beta = 0.3;
@@ -226,6 +292,20 @@ static void shim_scenarios(void) {
   a[4] = rmock_real(&vf2, 1, -1, 0); a[5] = rmock_real(Rinv, N * N, N, N); a[6] = rmock_real(&s2, 1, -1, 0);
   r = call("ccgp_R_predict_from_factors", 7, a);
   CHECK(r && rmock_length(r) == 4, "predict_from_factors is m x 2");
+  {
+    /* predict.post on one full frame row; on a slim row: warning + NA */
+    const int len = 3 + 2 + 2 * N + N * N, w0 = rmock_n_warnings();
+    double* prow = filled(len, 0.3);
+    double xr[D] = {0.2, 0.4, 0.6};
+    a[0] = rmock_real(xr, D, -1, 0); a[1] = rmock_real(X, N * D, N, D); a[2] = rmock_real(prow, len, -1, 0);
+    a[3] = rmock_real(&s2, 1, -1, 0); a[4] = rmock_int(&zero, 1); a[5] = rmock_real(&zero_d, 1, -1, 0);
+    r = call("ccgp_R_predict_post", 6, a);
+    CHECK(r && rmock_length(r) == 2 && !rmock_is_na_real(reals(r)[0]) && rmock_n_warnings() == w0, "predict.post -> cbind(mean, var)");
+    a[2] = rmock_real(prow, 4, -1, 0);
+    r = call("ccgp_R_predict_post", 6, a);
+    CHECK(r && rmock_is_na_real(reals(r)[0]) && rmock_is_na_real(reals(r)[1]) && rmock_n_warnings() == w0 + 1, "slim row -> warning + NA");
+    free(prow);
+  }
   a[0] = rmock_real(Rinv, N * N, N, N); a[1] = rmock_real(y, N, -1, 0);
   call("ccgp_R_beta_mle", 2, a);
   a[2] = rmock_real(&beta, 1, -1, 0);
@@ -304,7 +384,7 @@ static void shim_scenarios(void) {
   unsetenv("CCGP_DEVICES");
   rmock_reset();
   free(X); free(y); free(th); free(Xn); free(row); free(params); free(ll_keep); free(mean_keep); free(Xt); free(Rinv); free(rr);
-  free(Xs); free(row2);
+  free(Xs); free(row2); free(fr);
 }
 
 int main(void) {

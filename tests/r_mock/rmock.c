@@ -299,6 +299,14 @@ SEXP rmock_int(const int* v, R_xlen_t n) {
   return o;
 }
 SEXP rmock_nil(void) { return R_NilValue; }
+/* a data frame as .Call sees it: a VECSXP of columns with a `names` attribute (n_names = 0: unnamed list) */
+SEXP rmock_list(R_xlen_t n) { return Rf_allocVector(VECSXP, n); }
+void rmock_list_set(SEXP l, R_xlen_t i, SEXP v) { SET_VECTOR_ELT(l, i, v); }
+void rmock_list_names(SEXP l, const char** names, int n_names) {
+  SEXP s = Rf_allocVector(STRSXP, n_names);
+  for (int i = 0; i < n_names; ++i) SET_STRING_ELT(s, i, Rf_mkChar(names[i]));
+  Rf_setAttrib(l, R_NamesSymbol, s);
+}
 int rmock_typeof(SEXP x) { return x->type; }
 long rmock_length(SEXP x) { return (long)x->length; }
 int rmock_dim(SEXP x, int which) { return x->dim == R_NilValue ? -1 : ((int*)x->dim->data)[which]; }

@@ -48,6 +48,12 @@ class MockR:
         L.rmock_int.restype = vp
         L.rmock_int.argtypes = [_ip, ctypes.c_ssize_t]
         L.rmock_nil.restype = vp
+        L.rmock_list.restype = vp
+        L.rmock_list.argtypes = [ctypes.c_ssize_t]
+        L.rmock_list_set.restype = None
+        L.rmock_list_set.argtypes = [vp, ctypes.c_ssize_t, vp]
+        L.rmock_list_names.restype = None
+        L.rmock_list_names.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
         for name, res, args in (("rmock_typeof", ctypes.c_int, [vp]), ("rmock_length", ctypes.c_long, [vp]),
                                 ("rmock_dim", ctypes.c_int, [vp, ctypes.c_int]), ("rmock_data", vp, [vp]),
                                 ("rmock_elt", vp, [vp, ctypes.c_long]), ("rmock_names", vp, [vp]),
@@ -75,6 +81,19 @@ class MockR:
     def integer(self, a):
         f = np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.int32)))
         return self.L.rmock_int(f.ctypes.data_as(_ip), f.size)
+
+    def frame(self, table, names=None, integer_columns=()):
+        """2-D numpy table -> data.frame as .Call sees one: a VECSXP of REALSXP columns (INTSXP for the listed column
+        indices: read.table gives integer columns for whole numbers) with a `names` attribute."""
+        table = np.asarray(table, dtype=np.float64)
+        lst = self.L.rmock_list(table.shape[1])
+        for j in range(table.shape[1]):
+            col = self.integer(table[:, j]) if j in integer_columns else self.real(table[:, j])
+            self.L.rmock_list_set(lst, j, col)
+        if names is not None:
+            arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+            self.L.rmock_list_names(lst, arr, len(names))
+        return lst
 
     def null(self):
         return self.L.rmock_nil()

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_gv, load_hyper, load_qian, synthetic_design
+from conftest import ROOT, load_gv, load_hyper, load_maximin, load_qian, synthetic_design
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "r_mock"))
 import rmock  # noqa: E402
@@ -77,14 +77,20 @@ def test_logpost_list_val_beta_rinv(R, handle):
     theta_t = np.array([np.log(0.3), np.log(15.0), np.log(4.0)])
     pars = np.array([7.0, 3.0, 3.0, 28.0])
     got = R.dot_call("ccgp_R_logpost", R.real(D), R.real(theta_t), R.real(y), R.real(s2), R.integer(api.PRIOR_INVGAMMA),
-                     R.real(pars))
+                     R.real(pars), R.integer(1))
     assert list(got) == ["val", "beta", "R.Inv", "loglik"]            # r/ccgp.R reads r$val, r$beta, r$R.Inv, r$loglik
     want = handle.logpost(D, y, s2, api.PRIOR_INVGAMMA, theta_t, pars)
     assert got["val"][0] == want["val"] and got["beta"][0] == want["beta"] and got["loglik"][0] == want["loglik"]
     assert got["R.Inv"].shape == (64, 64) and np.array_equal(got["R.Inv"], want["R_inv"])
     # scripts whose logpost takes no prior parameters pass NULL (GV:429-454)
-    got = R.dot_call("ccgp_R_logpost", R.real(D), R.real(theta_t), R.real(y), R.real(s2), R.integer(api.PRIOR_GV), R.null())
+    got = R.dot_call("ccgp_R_logpost", R.real(D), R.real(theta_t), R.real(y), R.real(s2), R.integer(api.PRIOR_GV), R.null(),
+                     R.integer(1))
     assert got["val"][0] == handle.logpost(D, y, s2, api.PRIOR_GV, theta_t)["val"]
+    # slim frame (r/ccgp.R, ccgp.slim.frame): solve(R) is neither formed nor shipped, Metro stores the 1 x 1 placeholder
+    slim = R.dot_call("ccgp_R_logpost", R.real(D), R.real(theta_t), R.real(y), R.real(s2), R.integer(api.PRIOR_GV), R.null(),
+                      R.integer(0))
+    assert slim["R.Inv"].shape == (1,) and slim["R.Inv"][0] == 0.0
+    assert abs(slim["val"][0] - got["val"][0]) <= 1e-12 * abs(got["val"][0]) and abs(slim["beta"][0] - got["beta"][0]) <= 1e-12
     assert R.warnings() == []
 
 
@@ -95,7 +101,7 @@ def test_logpost_singular_design_gives_na_like_try_solve(R):
     D = np.array([[0.1, 0.2], [0.3, 0.8], [0.7, 0.9], [0.4, 0.5]])
     y = np.array([1.0, 2.0, 3.0, 4.0])
     got = R.dot_call("ccgp_R_logpost", R.real(D), R.real([-800.0, -800.0, 0.0]), R.real(y), R.real(1.0),
-                     R.integer(api.PRIOR_ISO), R.null())
+                     R.integer(api.PRIOR_ISO), R.null(), R.integer(1))
     assert R.is_na(got["val"]).all() and R.is_na(got["beta"]).all() and R.is_na(got["loglik"]).all()
     assert got["R.Inv"].dtype == np.int32 and got["R.Inv"].shape == (1,) and got["R.Inv"][0] == -2 ** 31   # logical NA
     assert R.warnings() == []            # a failed factorisation is a result, not an error
@@ -178,6 +184,145 @@ def test_literal_predict_post_factors_beta_sigma2(R, handle):
     assert s[0] == handle.sigma2_mle(Rinv, y, beta)
 
 
+# ---- the prediction phase of the unchanged scripts: frame -> ONE table (r/ccgp.R's compare.GP / prediction wrappers) ----
+def _gv_frame(handle, S=6, size=50, seed=7):
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, Dt, _ = load_gv(size)
+    rng = np.random.default_rng(seed)
+    draws = np.column_stack([rng.uniform(0.5, 0.9, S), rng.uniform(0.2, 0.5, S), rng.uniform(10, 20, S)])
+    gp = CombinedGP("GV", handle=handle)
+    frame = gp.factors_frame_from_draws(draws, D, 10.0, y)           # S x (5 + 2n + n^2), HX:625-644's layout
+    P = gp.draws_to_params(D, draws)
+    return D, y, Dt, draws, frame, P
+
+
+def test_prediction_table_from_a_factors_frame_is_predict_batch_bit_for_bit(R, handle):
+    """ccgp_R_prediction_table(pars.frame, D.train, D.test, sigma2, y.train, layout, nu): what compare.GP needs for a
+    whole test set (HX:713-725, GV:648-676) from the frame factors.frame returned -- as a data frame (list of columns),
+    as a numeric matrix, wide (5 + 2n + n^2 columns) or slim (p, theta1, theta2, beta) -- in one ccgp_predict_batch."""
+    D, y, Dt, draws, frame, P = _gv_frame(handle)
+    S, n = frame.shape[0], D.shape[0]
+    assert frame.shape[1] == 5 + 2 * n + n * n
+    mean, var, beta, _ = handle.predict_batch(D, y, 2, P, Dt, 10.0)
+    args = lambda fr: (fr, R.real(D), R.real(Dt), R.real(10.0), R.real(y), R.integer(0), R.real(0.0))
+    for fr in (R.frame(frame), R.real(frame), R.frame(frame[:, :4], names=["p", "theta1", "theta2", "beta"]),
+               R.real(frame[:, :3])):
+        got = R.dot_call("ccgp_R_prediction_table", *args(fr))
+        assert got[0].shape == (S, 150) and np.array_equal(got[0], mean) and np.array_equal(got[1], var)
+        assert np.array_equal(got[2], beta)
+    # the frame's own beta column is what the device recomputes (factors.frame stores Metro's beta, HX:638)
+    assert np.allclose(frame[:, 3], beta, rtol=1e-10, atol=0)
+    # a draws table read from a file may carry an integer column
+    whole = frame[:, :3].copy()
+    whole[:, 2] = np.round(whole[:, 2])
+    got = R.dot_call("ccgp_R_prediction_table", *args(R.frame(whole, integer_columns=(2,))))
+    want = handle.predict_batch(D, y, 2, np.array([iso_row(r[0], r[1], r[2], 9) for r in whole]), Dt, 10.0)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert R.warnings() == []
+    # a draw whose factorisation fails (theta = 0: R = 11'): NA_real_ in its row only
+    bad = frame[:, :4].copy()
+    bad[2, 1:3] = 0.0
+    got = R.dot_call("ccgp_R_prediction_table", *args(R.real(bad)))
+    assert R.is_na(got[0][2]).all() and R.is_na(got[1][2]).all() and not R.is_na(got[0][[0, 1, 3, 4, 5]]).any()
+    assert np.array_equal(got[0][[0, 1, 3, 4, 5]], mean[[0, 1, 3, 4, 5]])
+    # shapes that do not fit the layout: warning + NA, never an error
+    got = R.dot_call("ccgp_R_prediction_table", R.real(frame[:, :2]), R.real(D), R.real(Dt), R.real(10.0), R.real(y),
+                     R.integer(0), R.real(0.0))
+    assert R.is_na(got[0]).all() and "do not fit layout" in R.warnings()[0]
+
+
+def test_table_cache_lookup_clear_serves_prediction_row_by_row(R, handle):
+    """compare.GP's wrapper: ccgp_R_table_cache once, then the script's own apply_pb(D.test, 1, prediction, ...) asks for
+    each row of D.test in turn (HX:719); ccgp_R_table_lookup returns the 2 x S block (rows mean, var) that
+    apply(pars.frame, 1, predict.post, ...) would have produced (HX:688 transposes it)."""
+    D, y, Dt, draws, frame, P = _gv_frame(handle, S=5)
+    S = frame.shape[0]
+    mean, var, _, _ = handle.predict_batch(D, y, 2, P, Dt, 10.0)
+    k = R.dot_call("ccgp_R_table_cache", R.frame(frame[:, :4]), R.real(D), R.real(Dt), R.real(10.0), R.real(y), R.integer(0),
+                   R.real(0.0))
+    assert k[0] == S
+    order = list(range(150)) + [3, 149, 0, 77]           # in order (apply), then out of order (a user's own loop)
+    for t in order:
+        blk = R.dot_call("ccgp_R_table_lookup", R.real(Dt[t]), R.integer(S))
+        assert blk.shape == (2, S) and np.array_equal(blk[0], mean[:, t]) and np.array_equal(blk[1], var[:, t])
+    assert R.dot_call("ccgp_R_table_lookup", R.real(Dt[0] + 1e-9), R.integer(S)) is None        # not a row of D.test
+    assert R.dot_call("ccgp_R_table_lookup", R.real(Dt[0]), R.integer(S + 1)) is None           # another frame
+    assert R.dot_call("ccgp_R_table_lookup", R.real(Dt[0, :5]), R.integer(S)) is None           # another dimension
+    assert R.dot_call("ccgp_R_table_clear") is None
+    assert R.dot_call("ccgp_R_table_lookup", R.real(Dt[0]), R.integer(S)) is None
+    # a failing table call leaves nothing cached
+    k = R.dot_call("ccgp_R_table_cache", R.real(frame[:, :2]), R.real(D), R.real(Dt), R.real(10.0), R.real(y), R.integer(0),
+                   R.real(0.0))
+    assert k[0] == 0 and R.dot_call("ccgp_R_table_lookup", R.real(Dt[0]), R.integer(S)) is None
+    assert len(R.warnings()) == 1
+
+
+def test_predict_post_parses_the_frame_row_in_c(R, handle):
+    """predict.post(x.new, D.train, pars, sigma2) HX:655-673 on ONE frame row: r/ccgp.R passes the row as it is, every
+    index (beta at 4 / 5, mean.factor, var.factor1, var.factor2, R.Inv: HX:659-663, ANI:611-615) is computed in the shim.
+    Same bits as Mixed.corr.vec + the literal arithmetic, and the batched table to rounding."""
+    from ccgp_amd.rsurface import CombinedGP
+    D, y, Dt, draws, frame, P = _gv_frame(handle, S=3)
+    n = D.shape[0]
+    mean, var, _, _ = handle.predict_batch(D, y, 2, P, Dt, 10.0)
+    for s in range(3):
+        row = frame[s]
+        got = R.dot_call("ccgp_R_predict_post", R.real(Dt[5]), R.real(D), R.real(row), R.real(10.0), R.integer(0), R.real(0.0))
+        assert got.shape == (1, 2)
+        r = handle.mixed_corr_cross(Dt[5:6], D, 2, P[s])
+        m, v = handle.predict_from_factors(r, row[3], row[4:4 + n], row[4 + n:4 + 2 * n], row[4 + 2 * n],
+                                           row[5 + 2 * n:].reshape(n, n, order="F"), 10.0)
+        assert got[0, 0] == m[0] and got[0, 1] == v[0]
+        assert got[0, 0] == pytest.approx(mean[s, 5], rel=1e-9) and got[0, 1] == pytest.approx(var[s, 5], rel=1e-7)
+    # several sites at once: x.new as an m x d matrix -> m rows of cbind(mean, var)
+    got = R.dot_call("ccgp_R_predict_post", R.real(Dt[:7]), R.real(D), R.real(frame[0]), R.real(10.0), R.integer(0), R.real(0.0))
+    assert got.shape == (7, 2) and np.allclose(got[:, 0], mean[0, :7], rtol=1e-9)
+    assert R.warnings() == []
+    # the anisotropic script: four leading columns, beta at pars[5] (ANI:604-623)
+    Dm = load_maximin(14)
+    ym = np.sin(3 * Dm[:, 0]) + Dm[:, 1] ** 2
+    gpa = CombinedGP("ANI", handle=handle)
+    fa = gpa.factors_frame_from_draws([(0.7, 1.5, 2.5, 4.0)], Dm, 2.0, ym)
+    x = np.array([0.1, -0.3])
+    got = R.dot_call("ccgp_R_predict_post", R.real(x), R.real(Dm), R.real(fa[0]), R.real(2.0), R.integer(2), R.real(0.0))
+    want = gpa.predict_post(x, Dm, fa[0], 2.0)
+    assert np.array_equal(got, want)
+    tab = R.dot_call("ccgp_R_prediction_table", R.real(fa[:, :4]), R.real(Dm), R.real(x[None]), R.real(2.0), R.real(ym),
+                     R.integer(2), R.real(0.0))
+    assert tab[0][0, 0] == pytest.approx(got[0, 0], rel=1e-9) and tab[1][0, 0] == pytest.approx(got[0, 1], rel=1e-7)
+    # ADV as written: the second scale is theta1 (1 + pars[3]) (ADV:672)
+    gpv = CombinedGP("ADV", handle=handle)
+    fv = gpv.factors_frame_from_draws([(0.7, 1.5, 2.5)], Dm, 2.0, ym)
+    got = R.dot_call("ccgp_R_predict_post", R.real(x), R.real(Dm), R.real(fv[0]), R.real(2.0), R.integer(1), R.real(0.0))
+    assert np.array_equal(got, gpv.predict_post(x, Dm, fv[0], 2.0))
+    # a slim frame row has no cached terms: warning + NA
+    got = R.dot_call("ccgp_R_predict_post", R.real(x), R.real(Dm), R.real(fv[0, :4]), R.real(2.0), R.integer(0), R.real(0.0))
+    assert R.is_na(got).all() and "slim" in R.warnings()[-1]
+
+
+def test_one_dimensional_layouts_select_their_family_for_the_call(R, handle):
+    """Layouts 3 / 4: the Matern and Matern + spline families of the 1-D scripts (D1:794-812, D1F:737-754) are selected
+    for the duration of the table call and the handle is Gaussian again afterwards."""
+    from ccgp_amd import api
+    X = np.linspace(0.02, 0.98, 12)[:, None]
+    y = np.sin(6 * X[:, 0]) + 0.3 * X[:, 0]
+    Xt = np.linspace(0.1, 0.9, 5)[:, None]
+    draws = np.array([[0.7, 0.4, 0.15], [0.6, 0.5, 0.2]])
+    P = np.array([[r[0], 1 - r[0], r[1], r[2]] for r in draws])
+    for layout, fam in ((3, api.KERNEL_MATERN), (4, api.KERNEL_MATERN_SPLINE)):
+        got = R.dot_call("ccgp_R_prediction_table", R.real(draws), R.real(X), R.real(Xt), R.real(1.5), R.real(y),
+                         R.integer(layout), R.real(5.0))
+        handle.set_kernel(fam, 5.0)
+        try:
+            want = handle.predict_batch(X, y, 2, P, Xt, 1.5)
+        finally:
+            handle.set_kernel(api.KERNEL_GAUSS)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # back to Gaussian for the next call
+        assert np.array_equal(R.dot_call("ccgp_R_corr_matrix", R.real(X), R.real([0.4])), handle.corr_matrix(X, [0.4]))
+    assert R.warnings() == []
+
+
 def test_mixed_logdet_designs(R, handle):
     rng = np.random.default_rng(11)
     designs = rng.random((6, 14, 2))
@@ -238,6 +383,11 @@ def test_ccgp_devices_routes_the_batched_calls_through_ccgp_multi(R, handle):
         assert np.array_equal(got[0], ll) and np.array_equal(got[1], beta)
         got = R.dot_call("ccgp_R_predict_batch", R.real(D), R.real(y), R.integer(2), R.real(P), R.real(Dt[:20]), R.real(10.0))
         mean, var, b2, _ = handle.predict_batch(D, y, 2, P, Dt[:20], 10.0)
+        assert np.array_equal(got[0], mean) and np.array_equal(got[1], var) and np.array_equal(got[2], b2)
+        # the frame-driven table of compare.GP's wrapper is sharded over the draws as well
+        fr = np.column_stack([P[:, 0], P[:, 2], P[:, 11]])                  # (p, theta1, theta2) back from the rows
+        got = R.dot_call("ccgp_R_prediction_table", R.real(fr), R.real(D), R.real(Dt[:20]), R.real(10.0), R.real(y),
+                         R.integer(0), R.real(0.0))
         assert np.array_equal(got[0], mean) and np.array_equal(got[1], var) and np.array_equal(got[2], b2)
         got = R.dot_call("ccgp_R_grid_marginal", R.real(Dq), R.real(yq), R.real(62.0), R.real(H), R.integer(200), R.real(50.0),
                          R.integer(1), R.real(-1.0))

@@ -126,11 +126,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   typedef double d8 __attribute__((ext_vector_type(8)));
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const double* __restrict__ bcol = SCOL ? a.colpad + j0 + wave_u * JW : nullptr;
-#ifdef CCGP_ABL_COV_NOLOOP   // timing ablation only: what a tile costs without its entries (prologue + stores)
-  for (int c = 0; c < K * (int)(a.sigma2 == 12345.678); ++c) {
-#else
   for (int c = 0; c < K; ++c) {
-#endif
     double sdot[JW];
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) sdot[jj] = 0.0;
@@ -165,9 +161,6 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
     if (a.lower_tiles) {
       if (gi >= a.n || gj >= a.n) v = (gi == gj) ? 1.0 : 0.0;  // identity padding
     }
-#ifdef CCGP_ABL_COV_NOSTORE   // timing ablation only
-    if (v == 12345.678)
-#endif
     if (gi < rows_valid) out[gi + (size_t)gj * a.ldo] = v;
   }
 }

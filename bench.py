@@ -201,6 +201,30 @@ def cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core, one_core_evals
                        else "built-in C Cholesky (no LAPACK found)")}
 
 
+def cpu_gradient_fd(X, y, P, K, sigma2, per_core=100):
+    """The stated CPU baseline of the gradient: the reference has no analytic gradient -- LearnBayes::laplace differences
+    logpost numerically (HX:493) -- so the baseline is the compiled evaluator with CENTRAL DIFFERENCES in every parameter
+    (2 P likelihood evaluations per gradient), OpenMP over evaluations on every core."""
+    from oracle.cpu_baseline import loader as cpu
+    cores = cpu.max_threads()
+    B = min(P.shape[0], per_core * cores)
+    Pn = P.shape[1]
+    h = 1e-4     # relative step: the likelihood itself carries cond(R) eps of rounding, so smaller steps only add noise
+    big = np.repeat(P[:B], 2 * Pn, axis=0)
+    for j in range(Pn):
+        big[2 * j::2 * Pn, j] += h * np.abs(P[:B, j])
+        big[2 * j + 1::2 * Pn, j] -= h * np.abs(P[:B, j])
+    cpu.loglik_batch(X, y, K, big[:2 * Pn * cores], sigma2, 0, 0.0, threads=cores)      # warm the OpenMP team
+    t0 = time.perf_counter()
+    ll = cpu.loglik_batch(X, y, K, big, sigma2, 0, 0.0, threads=cores)[0]
+    t_all = time.perf_counter() - t0
+    ll = np.asarray(ll).reshape(B, Pn, 2)
+    g = (ll[:, :, 0] - ll[:, :, 1]) / (2 * h * np.abs(P[:B]))
+    return {"all_cores": B / t_all, "cores": cores, "unit": "gradients/s",
+            "sample": "%d gradients = %d likelihood evaluations (central differences in %d parameters) on %d cores in %.2f s"
+                      % (B, B * 2 * Pn, Pn, cores, t_all)}, g
+
+
 def cpu_reference_opcount(workload, X, y, P, K, sigma2, mode, tau2, budget_s=8.0):
     """The oracle (numpy restatement of the reference's R operation sequence: materialised U + t(U) + V
     temporaries, LU inverse via solve(), then dmnorm's chol + chol2inv) timed with numpy's BLAS threads: an
@@ -450,6 +474,7 @@ def run_loglik_workload(c):
             cpu_sec["cfg3"] = cpu_compiled_loglik(X3, y3, P3, K3, s23, api.MEAN_ZERO_PLUS_TAU2, 1e4, 800, 2000)
             cpu_sec["cfg5"] = cpu_predict_sample(*sec_in["cfg5"])
             cpu_sec["logpost"] = cpu_logpost_latency(X2, y2, s22)
+            cpu_sec["gradient"], cpu_sec["gradient_fd"] = cpu_gradient_fd(X2, y2, P2, K2, s22)
             if args.n == 4096:
                 cpu_sec["cfg4_predict"] = cpu_predict_n4096(X, y, K, P[:CFG4_PREDICT_DRAWS], sigma2)
 
@@ -742,7 +767,7 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
     # the north_star's "+ gradient": ccgp_loglik_grad_batch (host pointers) on the Heat-Exchanger design, next to the
     # same call without the gradient
     Bg = 65536
-    Pg = P2[:Bg]
+    Pg = np.asfortranarray(P2[:Bg])      # column-major on the host already, as R hands a matrix over
     h.loglik_grad_batch(X2, y2, K2, Pg, s22)
     t1 = time.perf_counter()
     _, _, gg, stg = h.loglik_grad_batch(X2, y2, K2, Pg, s22)
@@ -755,7 +780,12 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
                               "(host pointers, PCIe-inclusive)" % Bg,
                   "value": Bg / t_g, "unit": "gradients/s", "ms_per_call": 1e3 * t_g,
                   "ms_same_call_without_gradient": 1e3 * t_l, "failed": int((stg != 0).sum()),
-                  "all_finite": bool(np.isfinite(gg).all()), "cpu": None})
+                  "all_finite": bool(np.isfinite(gg).all()), "cpu": cpu_sec.get("gradient"),
+                  "rel_dev_from_cpu_central_differences_median_p99": (
+                      [float(v) for v in np.percentile(
+                          np.abs(gg[:cpu_sec["gradient_fd"].shape[0]] - cpu_sec["gradient_fd"]) /
+                          (np.abs(cpu_sec["gradient_fd"]) + 1e-3 * np.abs(cpu_sec["gradient_fd"]).max(axis=1, keepdims=True)), [50, 99])]
+                      if "gradient_fd" in cpu_sec else None)})
     # prediction at a second test set from factors kept in HBM, against re-factorising
     if args.workload == "cfg4" and X.shape[0] == 4096:
         Sf, mf_ = CFG4_PREDICT_DRAWS, CFG4_PREDICT_SITES

@@ -24,6 +24,8 @@
 //
 // Bound: neither HBM nor MFMA -- n dependent elimination steps; algorithmic HBM traffic per
 // evaluation is the parameter row in (8 P bytes) and 20 bytes out.
+#include <type_traits>
+
 #include "ccgp_internal.h"
 
 namespace ccgp {
@@ -60,10 +62,12 @@ struct RegArgs {
 
 // doubles of LDS per matrix, from the ACTUAL number of components and dimensions (round 3: sized for kMaxK / kMaxD
 // before -- 4 KB of th[] per matrix for a 2 x 4 table -- which left the prediction instances one workgroup per CU short)
+constexpr int kGradSlots = 28;   // accumulators of one pass of the gradient contraction: QG (1 + KG) <= 27
 __host__ __device__ constexpr int kPerMat(int NP, int G, int NE, int K, int d, bool inv = false) {
   return K * NP /*us*/ + K * d /*th*/ + K /*w2*/ + 2 * (NP + G * NE) /*colbuf*/ + NP /*dvec*/ +
          2 * NP /*zb*/ + 8 +
-         (inv ? NP * (NP + 1) /*Z, row stride NP + 1*/ : (NE > 1 ? K * G * NE /*ut*/ + 3 * G * G * NE /*partial sums*/ : 0));
+         (inv ? NP * (NP + 2) + 1 /*Z, row stride NP + 2, 16-byte aligned*/ + 4 * kGradSlots /*wave partial sums of the gradient*/
+              : (NE > 1 ? K * G * NE /*ut*/ + 3 * G * G * NE /*partial sums*/ : 0));
 }
 constexpr int kSmallExpTable = CCGP_SMALL_EXP_TABLE ? kExpTableDoubles : 0;
 
@@ -128,7 +132,8 @@ void small_reg_kernel(RegArgs a) {
   double* zb = dvec + NP;                     // [2][NP]
   double* ut = zb + 2 * NP + 8;               // [K][XR]   (NE > 1, prediction)
   double* psum = ut + K * XR;                 // [3][XR][G] (NE > 1, prediction)
-  double* zmat = zb + 2 * NP + 8;             // [NP][NP + 1] (INV): row t = L'^-1 e_t
+  double* zmat = zb + 2 * NP + 8;             // [NP][NP + 2] (INV): row t = L'^-1 e_t, columns scaled by d_c^-1/2
+  zmat += (zmat - smem) & 1;                  // its rows are read two doubles at a time (ds_read_b128)
   const int t0 = blockIdx.y * MT;             // first test site of this chunk
   double* xt = xs + (size_t)d * n + (size_t)MPW * PM;     // [d][XR], shared by the workgroup (NE > 1)
 
@@ -290,7 +295,8 @@ void small_reg_kernel(RegArgs a) {
 #pragma unroll
         for (int aa = kb; aa < NB; ++aa) cb[ty + G * aa] = M[aa][kb];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) cb[NP + ty + G * e] = E[e][kb];
+        for (int e = 0; e < NE; ++e)
+          if (!INV || e < kb + 2) cb[NP + ty + G * e] = E[e][kb];
       }
       mat_sync<G>();
       // every thread of the matrix reads the same word; handing it over through v_readfirstlane tells the compiler
@@ -320,15 +326,21 @@ void small_reg_kernel(RegArgs a) {
       if constexpr (!FULL) {
         if (ty <= kk) lr[kb] = 0.0;   // rows <= k are finished
       }
+      // identity rows (INV): row 2 + t = e_t' is still exactly zero left of column t, so at step k only the rows
+      // t <= k have anything to subtract: extra-row blocks e > (k + 2) / G are skipped (kb is unrolled: static)
+      constexpr int NEmax = NE;
+      const int ne_live = INV ? (kb + 2 < NEmax ? kb + 2 : NEmax) : NEmax;
       double le[NE];
 #pragma unroll
-      for (int e = 0; e < NE; ++e) le[e] = cb[NP + ty + G * e];
+      for (int e = 0; e < NE; ++e)
+        if (e < ne_live) le[e] = cb[NP + ty + G * e];
 #pragma unroll
       for (int bb = kb; bb < NB; ++bb) {
 #pragma unroll
         for (int aa = bb; aa < NB; ++aa) M[aa][bb] = fma(-lr[aa], lc[bb], M[aa][bb]);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) E[e][bb] = fma(-le[e], lc[bb], E[e][bb]);
+        for (int e = 0; e < NE; ++e)
+          if (e < ne_live) E[e][bb] = fma(-le[e], lc[bb], E[e][bb]);
       }
       cur ^= 1;
     }
@@ -386,10 +398,16 @@ void small_reg_kernel(RegArgs a) {
     }
   }
   if constexpr (INV) {
-    // R^-1 = Z' D^-1 Z with Z[t][c] = (L'^-1)[c][t] (zero for c < t): Z to LDS (row stride NP + 1: the threads of a
-    // wave read consecutive rows), 1 / d_c in place of d_c, then every thread forms its share of the lower triangle
-    constexpr int ZS = NP + 1;
+    // R^-1 = Z' D^-1 Z with Z[t][c] = (L'^-1)[c][t] (zero for c < t).  Round 4: the columns are scaled by d_c^-1/2 on the
+    // way to LDS, so an entry of R^-1 is a plain dot product of two rows -- two LDS reads and one FMA per term instead of
+    // three reads, a multiplication and an FMA -- and the row stride NP + 2 keeps 16-byte alignment: the dot products
+    // start at the even column below i (the entries left of the diagonal are exact zeros) and read two terms per
+    // ds_read_b128 (conflict-free: consecutive lanes are 2 (NP + 2) dwords = 4 banks mod 64 apart).
+    constexpr int ZS = NP + 2;
+    typedef double d2v __attribute__((ext_vector_type(2)));
     const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+    mat_sync<G>();
+    for (int c = lt; c < NP; c += TPM) dvec[c] = (bad || c >= n) ? 0.0 : sqrt(1.0 / dvec[c]);
     mat_sync<G>();
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -397,18 +415,28 @@ void small_reg_kernel(RegArgs a) {
 #pragma unroll
       for (int bb = 0; bb < NB; ++bb) {
         const int c = tx + G * bb;
-        if (t >= 0 && t < n && c < n) zmat[t * ZS + c] = E[e][bb];
+        if (t >= 0 && t < NP) zmat[t * ZS + c] = (t < n && c < n) ? E[e][bb] * dvec[c] : 0.0;
       }
     }
-    for (int c = lt; c < n; c += TPM) dvec[c] = bad ? 0.0 : 1.0 / dvec[c];
     mat_sync<G>();
+    // rows i and j of the scaled Z: sum over c >= i (i >= j), two terms per step
+    auto row_dot = [&](int i, int j) {
+      const d2v* zi = reinterpret_cast<const d2v*>(zmat + i * ZS);
+      const d2v* zj = reinterpret_cast<const d2v*>(zmat + j * ZS);
+      double acc0 = 0.0, acc1 = 0.0;
+      for (int h = i >> 1; h < NP / 2; ++h) {
+        const d2v u = zi[h], v = zj[h];
+        acc0 = fma(u[0], v[0], acc0);
+        acc1 = fma(u[1], v[1], acc1);
+      }
+      return acc0 + acc1;
+    };
     if constexpr (INV == 1) {
       if (valid)
         for (int idx = lt; idx < n * n; idx += TPM) {
           const int i = idx % n, j = idx / n;
           if (i < j) continue;
-          double acc = 0.0;
-          for (int c = i; c < n; ++c) acc = fma(zmat[i * ZS + c] * dvec[c], zmat[j * ZS + c], acc);
+          double acc = row_dot(i, j);
           if (bad) acc = kNaN;
           a.Rinv[i + (size_t)j * n] = acc;
           a.Rinv[j + (size_t)i * n] = acc;
@@ -420,67 +448,91 @@ void small_reg_kernel(RegArgs a) {
       //   d loglik / d theta_qk = -  sigma2 w_q^2 sum_ab M_ab (x_ak - x_bk)^2 R_q,ab
       // (the profile-beta term drops out: d loglik / d beta = 0 at beta_hat).  R^-1 entries come from Z as in the
       // inverse; R_q is regenerated from X; every thread takes pairs (a >= b), off-diagonal pairs count twice.
-      constexpr int kGD = 16;                                  // dimensions per accumulator group
+      // Round 4: the pair's R^-1 entry (an n-long dot product: the O(n^3) part) and m = M_ab are formed ONCE per pass
+      // over the pairs, and a pass carries QG components x KG dimensions of accumulators -- K = 2, d = 4 (Heat Exchanger)
+      // or K = 3, d = 5 is ONE pass; round 3 walked the pairs K ceil(d / 16) times, recomputing R^-1 every time.
       double* alpha = colbuf;                                  // [NP]   (the column buffers are free now)
-      double* part = colbuf + NP;                              // [4][1 + kGD] wave partial sums
+      double* part = zmat + NP * ZS;                           // [4][kGradSlots] wave partial sums
       const double beta = zb[2 * NP];
+      double* resid = zb;                                      // (z_y - beta z_1)_c d_c^-1/2 in place of z_y
+      for (int c = lt; c < NP; c += TPM) resid[c] = c < n ? (zb[c] - beta * zb[NP + c]) * dvec[c] : 0.0;
+      mat_sync<G>();
       for (int i = lt; i < n; i += TPM) {
         double s = 0.0;
-        for (int c = i; c < n; ++c) s = fma(zmat[i * ZS + c] * dvec[c], zb[c] - beta * zb[NP + c], s);
+        for (int c = i; c < n; ++c) s = fma(zmat[i * ZS + c], resid[c], s);
         alpha[i] = s / cs;
       }
       mat_sync<G>();
-      const int P = K + K * d;
       const int lane64 = lt & 63, wv = lt >> 6;
-      for (int q = 0; q < K; ++q) {
-        const double wq = a.params[pb + (size_t)q * a.ldp];
-        for (int k0 = 0; k0 < d; k0 += kGD) {
-          double gs = 0.0, hk[kGD];
+      auto contract = [&](auto qg_tag, auto kg_tag) {
+        constexpr int QG = decltype(qg_tag)::value, KG = decltype(kg_tag)::value;
+        static_assert(QG * (1 + KG) <= kGradSlots, "wave partial sums");
+        for (int q0 = 0; q0 < K; q0 += QG) {
+          for (int k0 = 0; k0 < d; k0 += KG) {
+            double gs[QG], hk[QG][KG];
 #pragma unroll
-          for (int k = 0; k < kGD; ++k) hk[k] = 0.0;
-          if (!bad)
-            for (int idx = lt; idx < n * n; idx += TPM) {
-              const int i = idx % n, j = idx / n;
-              if (i < j) continue;
-              double rinv = 0.0;
-              for (int c = i; c < n; ++c) rinv = fma(zmat[i * ZS + c] * dvec[c], zmat[j * ZS + c], rinv);
-              const double m = (i == j ? 0.5 : 1.0) * (alpha[i] * alpha[j] - rinv / cs);
-              double sd = 0.0;
-              for (int k = 0; k < d; ++k) sd = fma(xs[k * n + i] * th[q * d + k], xs[k * n + j], sd);
-              const double dist = (us[q * NP + i] + us[q * NP + j]) + (-2.0 * sd);
-              const double v = m * exp_small<true>(dist, etab);
-              gs += v;
+            for (int qq = 0; qq < QG; ++qq) {
+              gs[qq] = 0.0;
 #pragma unroll
-              for (int k = 0; k < kGD; ++k)
-                if (k0 + k < d) {
-                  const double df = xs[(k0 + k) * n + i] - xs[(k0 + k) * n + j];
-                  hk[k] = fma(v, df * df, hk[k]);
+              for (int k = 0; k < KG; ++k) hk[qq][k] = 0.0;
+            }
+            if (!bad)
+              for (int idx = lt; idx < n * n; idx += TPM) {
+                const int i = idx % n, j = idx / n;
+                if (i < j) continue;
+                const double m = (i == j ? 0.5 : 1.0) * (alpha[i] * alpha[j] - row_dot(i, j) / cs);
+                double df2[KG];
+#pragma unroll
+                for (int k = 0; k < KG; ++k) {
+                  const int kk = k0 + k < d ? k0 + k : d - 1;
+                  const double df = xs[kk * n + i] - xs[kk * n + j];
+                  df2[k] = df * df;
                 }
-            }
-          for (int off = 32; off > 0; off >>= 1) {
-            gs += __shfl_xor(gs, off, 64);
 #pragma unroll
-            for (int k = 0; k < kGD; ++k)
-              if (k0 + k < d) hk[k] += __shfl_xor(hk[k], off, 64);
-          }
-          if (lane64 == 0) {
-            part[wv * (1 + kGD)] = gs;
+                for (int qq = 0; qq < QG; ++qq) {
+                  const int q = q0 + qq;
+                  if (q >= K) break;
+                  double sd = 0.0;
+                  for (int k = 0; k < d; ++k) sd = fma(xs[k * n + i] * th[q * d + k], xs[k * n + j], sd);
+                  const double dist = (us[q * NP + i] + us[q * NP + j]) + (-2.0 * sd);
+                  const double v = m * exp_small<true>(dist, etab);
+                  gs[qq] += v;
 #pragma unroll
-            for (int k = 0; k < kGD; ++k) part[wv * (1 + kGD) + 1 + k] = hk[k];
-          }
-          mat_sync<G>();
-          if (lt < 1 + kGD && valid) {
-            const double tot = (part[lt] + part[(1 + kGD) + lt]) + (part[2 * (1 + kGD) + lt] + part[3 * (1 + kGD) + lt]);
-            if (lt == 0) {
-              if (k0 == 0) a.grad[b + (size_t)q * a.Btot] = bad ? kNaN : 2.0 * a.sigma2 * wq * tot;
-            } else if (k0 + lt - 1 < d) {
-              a.grad[b + (size_t)(K + q * d + k0 + lt - 1) * a.Btot] = bad ? kNaN : -a.sigma2 * wq * wq * tot;
+                  for (int k = 0; k < KG; ++k) hk[qq][k] = fma(v, df2[k], hk[qq][k]);
+                }
+              }
+#pragma unroll
+            for (int qq = 0; qq < QG; ++qq) {
+              for (int off = 32; off > 0; off >>= 1) {
+                gs[qq] += __shfl_xor(gs[qq], off, 64);
+#pragma unroll
+                for (int k = 0; k < KG; ++k) hk[qq][k] += __shfl_xor(hk[qq][k], off, 64);
+              }
+              if (lane64 == 0) {
+                part[wv * kGradSlots + qq * (1 + KG)] = gs[qq];
+#pragma unroll
+                for (int k = 0; k < KG; ++k) part[wv * kGradSlots + qq * (1 + KG) + 1 + k] = hk[qq][k];
+              }
             }
+            mat_sync<G>();
+            if (lt < QG * (1 + KG) && valid) {
+              const int qq = lt / (1 + KG), slot = lt % (1 + KG), q = q0 + qq;
+              const double tot = (part[lt] + part[kGradSlots + lt]) + (part[2 * kGradSlots + lt] + part[3 * kGradSlots + lt]);
+              if (q < K) {
+                const double wq = a.params[pb + (size_t)q * a.ldp];
+                if (slot == 0) {
+                  if (k0 == 0) a.grad[b + (size_t)q * a.Btot] = bad ? kNaN : 2.0 * a.sigma2 * wq * tot;
+                } else if (k0 + slot - 1 < d) {
+                  a.grad[b + (size_t)(K + q * d + k0 + slot - 1) * a.Btot] = bad ? kNaN : -a.sigma2 * wq * wq * tot;
+                }
+              }
+            }
+            mat_sync<G>();
           }
-          mat_sync<G>();
         }
-      }
-      (void)P;
+      };
+      if (d <= 8) contract(std::integral_constant<int, 3>{}, std::integral_constant<int, 8>{});
+      else contract(std::integral_constant<int, 1>{}, std::integral_constant<int, 16>{});
     }
     return;
   }

@@ -42,13 +42,6 @@ namespace ccgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-#ifndef CCGP_DIAG_V2
-#define CCGP_DIAG_V2 1   // per-wave specialised k-loop of the diagonal workgroup (0: the round-2 loop, for A/B builds)
-#endif
-#ifndef CCGP_UPDATE_IL
-#define CCGP_UPDATE_IL 1   // whole update tiles through tile_accumulate_il (0: the round-2 loop, for A/B builds)
-#endif
-
 namespace {
 
 
@@ -513,7 +506,7 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
 
 
 // k-loop of the diagonal workgroup (see diag_rhs_tile below), one instantiation per wave W so that everything a
-// slot needs is a compile-time constant.  Against the round-2 loop (kept under CCGP_DIAG_V2 = 0):
+// slot needs is a compile-time constant.  Against the round-2 loop (below, now only the 64-bit-pointer fallback):
 //   * both operands come from the SAME panel image and the MFMA's A and B lane maps coincide (lane & 15 -> index,
 //     lane >> 4 -> k), so the fragment of block row r IS the fragment of column block r: a k-step loads the column
 //     blocks 0 .. max(W, 7 - W) once (plus 2W, 2W + 1 for the right-hand sides where they lie beyond, plus the
@@ -647,8 +640,10 @@ __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, co
   cbs[10] = 2 * wave + 1;
 
   // the specialised loop addresses its panel through 32-bit buffer offsets: matrices whose panel spans 4 GiB or
-  // more (n >= ~16 000 with the identity rows of an inverse below them) keep the 64-bit-pointer loop -- same bits
-  if (CCGP_DIAG_V2 && !wide && fits_buffer_offsets(Kdim, ld)) {
+  // more (n >= ~16 000 with the identity rows of an inverse below them) keep the 64-bit-pointer loop -- same bits.
+  // That older loop (the `else` branch) is kept for exactly this case and nothing else; CCGP_OPT_WIDE_OFFSETS forces it
+  // so that the tests can hold one loop against the other at sizes that fit a test (the OPT_WIDE_OFFSETS test of tests/test_gpu_parity.py).
+  if (!wide && fits_buffer_offsets(Kdim, ld)) {
     switch (wave) {
       case 0: diag_rhs_accumulate<0>(smem, Qp, Tp, ld, Kdim, acc); break;
       case 1: diag_rhs_accumulate<1>(smem, Qp, Tp, ld, Kdim, acc); break;
@@ -1000,7 +995,7 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   }
   if constexpr (MODE == 0 && S == 1) {
     if (ring) { gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
-    if (CCGP_UPDATE_IL && !g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
+    if (!g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
       update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
       return;
     }

@@ -214,6 +214,24 @@ def test_logpost_golden_every_script(handle):
         assert r["val"] == pytest.approx(c["val"], rel=1e-7)
         assert r["beta"] == pytest.approx(c["beta"], rel=1e-6, abs=1e-9)
         digest_close(r["R_Inv"], c["R_inv"], 1e-5)
+    # the loose bounds above are cond * eps, not slack: arbitrate the likelihood term of the best- and the
+    # worst-conditioned case at 50 digits (oracle/mp_check.py) -- device and oracle must both sit within cond * eps of it
+    def ani_draw(tt):
+        p, t1, t2, lam = 1.0 / (1.0 + math.exp(-tt[2])), math.exp(tt[0]), math.exp(tt[1]), math.exp(tt[3])
+        return orc.unpack_params(np.array([p, 1 - p, t1, t2, (1 + lam) * t1, (1 + lam) * t2]), 2, 2)
+    conds = [np.linalg.cond(orc.mixed_corr_matrix_general(D100, *ani_draw(c["theta_t"]))) for c in ga["cases"]]
+    for c in (ga["cases"][int(np.argmin(conds))], ga["cases"][int(np.argmax(conds))]):
+        tt = c["theta_t"]
+        w, Th = ani_draw(tt)
+        truth_ll, truth_beta = (float(v) for v in mp_check.loglik(D100, y100, w, Th, c["sigma2"], 0, 0.0))
+        cond = np.linalg.cond(orc.mixed_corr_matrix_general(D100, w, Th))
+        tol = 50 * cond * np.finfo(float).eps
+        r = gpa.logpost(D100, tt, y100, c["sigma2"])
+        prior_jac = orc.logpost(D100, tt, y100, c["sigma2"], "ANI")
+        extra = prior_jac["val"] - prior_jac["log_like"]            # log-Jacobian + log-prior (ANI:457-462): closed forms
+        assert abs((r["val"] - extra) - truth_ll) <= tol * abs(truth_ll) + 1e-9
+        assert abs(c["loglik"] - truth_ll) <= tol * abs(truth_ll) + 1e-9
+        assert abs(r["beta"] - truth_beta) <= tol * max(abs(truth_beta), 1.0)
 
     gv = golden("gv_golden.json")
     gpg = CombinedGP("GV", handle=handle)

@@ -24,6 +24,7 @@
 //
 // Bound: neither HBM nor MFMA -- n dependent elimination steps; algorithmic HBM traffic per
 // evaluation is the parameter row in (8 P bytes) and 20 bytes out.
+#include <cstdlib>
 #include <type_traits>
 
 #include "ccgp_internal.h"
@@ -104,7 +105,7 @@ __device__ __forceinline__ void mat_sync() {
 #endif
 // INV: 0 = none, 1 = explicit inverse (solve(R), HX:454), 2 = analytic gradient of the profile-beta log-likelihood
 template <int G, int NB, int NE, bool FULL = false, int INV = 0>
-__global__ __launch_bounds__(256, INV ? 1 : (NE > 1 ? CCGP_SMALL_OCC_PRED : (G == 8 ? CCGP_SMALL_OCC_G8 : CCGP_SMALL_OCC_G16)))
+__global__ __launch_bounds__(256, INV ? 1 : (NE > 1 ? CCGP_SMALL_OCC_PRED : (G == 8 ? (NB > 8 ? 2 : CCGP_SMALL_OCC_G8) : CCGP_SMALL_OCC_G16)))
 void small_reg_kernel(RegArgs a) {
   static_assert(!INV || (G == 16 && NE == NB + 1 && !FULL), "the inverse / gradient runs one matrix per workgroup with n identity rows");
   constexpr int TPM = G * G;       // threads per matrix
@@ -229,7 +230,11 @@ void small_reg_kernel(RegArgs a) {
         if (bb >= NB) continue;
         const int c = tx + G * bb;
 #pragma unroll
-        for (int aa = bb; aa < NB; ++aa) {
+        for (int aa = 0; aa < NB; ++aa) {
+          // constant trip count + a test that folds away: with `aa = bb` as the lower bound the unroller left this
+          // loop rolled for odd NB >= 9 (bb is only known once the two loops around it are unrolled), and ONE access
+          // with a run-time index puts the whole matrix in scratch (1.6 KB per lane at NB = 13)
+          if (aa < bb) continue;
           const int r = ty + G * aa;
           if constexpr (FULL) {
             // every (r, c) is a matrix entry; entries above the diagonal of the diagonal blocks (aa == bb, ty < tx)
@@ -740,6 +745,26 @@ static void dispatch(hipStream_t s, const RegArgs& a) {
   // LATENCY problem: one wave per matrix leaves the chip empty and runs the whole elimination on 64 lanes; the
   // 16 x 16 grid puts four waves on each matrix (n = 64, one evaluation: 41 -> 25 us of kernel time).
   const bool wide = NE == 1 && a.x_stride == 0 && a.B <= 64;
+  if constexpr (NE == 1) {
+    // 64 < n <= 104 (BASELINE config 3: maximin-100): still ONE WAVE per matrix on the 8 x 8 grid, with up to 13 x 13
+    // blocks per thread (two waves per SIMD: up to 256 VGPRs) -- at n = 100 1.68 x the minimal FMAs instead of the
+    // 2.75 x of the 16 x 16 grid at NB = 7, no s_barrier, and the per-column overhead (pivot, reciprocal, column
+    // broadcast) is paid by one wave instead of four: 25.7 k -> ~10 k VALU instructions per evaluation, 6.06 -> 5.07 ms
+    // per 103 680 evaluations on the same box, same bits (profiles/r04).  CCGP_NO_G8_WIDE=1: the 16 x 16 grid (A/B).
+    const int nb8 = (n + 7) / 8;
+    const bool fits8 = sizeof(double) * (kSmallExpTable + (size_t)a.d * n + (size_t)4 * kPerMat(8 * nb8, 8, 1, a.K, a.d) +
+                                         (a.x_stride ? (size_t)4 * a.d * n : 0)) <= (size_t)kLdsBytes - 64;   // four matrices per workgroup
+    if (n > 64 && n <= 104 && !wide && fits8 && getenv("CCGP_NO_G8_WIDE") == nullptr) {
+      switch ((n + 7) / 8) {
+        case 9: launch_one<8, 9, NE>(s, a); break;
+        case 10: launch_one<8, 10, NE>(s, a); break;
+        case 11: launch_one<8, 11, NE>(s, a); break;
+        case 12: launch_one<8, 12, NE>(s, a); break;
+        default: launch_one<8, 13, NE>(s, a); break;
+      }
+      return;
+    }
+  }
   if (n <= 64 && !wide) {
     switch ((n + 7) / 8) {
       case 1: launch_one<8, 1, NE>(s, a); break;

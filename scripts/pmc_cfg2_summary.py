@@ -4,8 +4,10 @@
 busy fractions.  SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles (MI355X guide, PMC table)."""
 import collections, csv, json, sys
 tag = sys.argv[1]
-wl = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'      # cfg2 (n = 64: one wave per evaluation) | cfg3 (n = 100: one workgroup of 4 waves)
-waves_per_eval = 1 if wl == 'cfg2' else 4
+wl = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'      # cfg2 (n = 64: one wave per evaluation) | cfg3 (n = 100)
+# cfg3: one workgroup of 4 waves per evaluation on the 16 x 16 grid (rounds 1 - 3, CCGP_NO_G8_WIDE=1), ONE wave per
+# evaluation on the 8 x 8 grid with 13 x 13 blocks per thread (round 4); pass 4 as third argument for the former
+waves_per_eval = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 tot = collections.defaultdict(float)
 launches = 0
 for i in (1, 2, 3):
@@ -20,7 +22,8 @@ waves = tot['SQ_WAVES'] / waves_per_eval     # = evaluations
 out = {"source": "rocprofv3 --pmc (three passes) --kernel-trace -- python3 bench.py --workload %s --steps 1 --warmup 1 --no-cpu-baseline; " % wl +
                  ("small_reg_kernel<8,8,1,full>, one wave per evaluation, 624 000 evaluations per launch" if wl == 'cfg2' else
                   "small_reg_kernel<16,7,1>, one workgroup (4 waves) per evaluation, 103 680 evaluations per launch; per-evaluation "
-                  "figures are sums over the 4 waves"),
+                  "figures are sums over the 4 waves" if waves_per_eval == 4 else
+                  "small_reg_kernel<8,13,1>, one wave per evaluation, 103 680 evaluations per launch"),
        "launches": launches, "raw": dict(tot)}
 if waves:
     per = lambda k: tot[k] / waves

@@ -153,15 +153,47 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
       accs[jj] = fma(wc, (FAM == 0 ? exp_cov(dist, etab) : corr_of_dist(a.fam, dist, etab, c)), accs[jj]);
     }
   }
+  if constexpr (SCOL) {
+    // lower-tile launches (the blocked path's matrix build): the tile lies inside the npad x npad array (npad a multiple
+    // of 64), so no bounds tests; the identity padding exists only in the tiles that reach past n -- a wave-uniform
+    // branch; and a column's address is base + lane * 8 + (column * ld * 8 in an SGPR): one buffer_store per output and
+    // NO vector address arithmetic.  Before, every output paid a 64-bit multiply-add for its address, two compares and
+    // selects for the padding and an exec-mask branch for the bounds: ~20 of the 102 VALU instructions per entry of a
+    // kernel whose VALU is busy 96 % of the time (profiles/r04/pmc_cov_summary.json).
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, -1, 0x00020000);
+    const unsigned voff = (unsigned)gi * 8u;
+    const unsigned col0 = (unsigned)(j0 + wave_u * JW);
+    const double scale = post_scale * inv_sw;
+    auto store = [&](int jj, double v) {
+      u2v bits;
+      bits[0] = (unsigned)__double2loint(v);
+      bits[1] = (unsigned)__double2hiint(v);
+      __builtin_amdgcn_raw_buffer_store_b64(bits, rout, voff, (col0 + (unsigned)jj) * (unsigned)a.ldo * 8u, 0);
+    };
+    if (i0 + kCovRows > a.n || j0 + kCovCols > a.n) {   // block-uniform: the tiles that reach into the identity padding
 #pragma unroll
-  for (int jj = 0; jj < JW; ++jj) {
-    const int gj = j0 + jl0 + jj;
-    if (gj >= cols_valid) break;
-    double v = fma(post_scale * inv_sw, accs[jj], post_shift);
-    if (a.lower_tiles) {
-      if (gi >= a.n || gj >= a.n) v = (gi == gj) ? 1.0 : 0.0;  // identity padding
+      for (int jj = 0; jj < JW; ++jj) {
+        const int gj = (int)col0 + jj;
+        double v = fma(scale, accs[jj], post_shift);
+        if (gi >= a.n || gj >= a.n) v = (gi == gj) ? 1.0 : 0.0;
+        store(jj, v);
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < JW; ++jj) store(jj, fma(scale, accs[jj], post_shift));
     }
-    if (gi < rows_valid) out[gi + (size_t)gj * a.ldo] = v;
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      const int gj = j0 + jl0 + jj;
+      if (gj >= cols_valid) break;
+      double v = fma(post_scale * inv_sw, accs[jj], post_shift);
+      if (a.lower_tiles) {
+        if (gi >= a.n || gj >= a.n) v = (gi == gj) ? 1.0 : 0.0;  // identity padding
+      }
+      if (gi < rows_valid) out[gi + (size_t)gj * a.ldo] = v;
+    }
   }
 }
 
@@ -215,7 +247,9 @@ void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv,
   cov_prepare();
   int nt64 = npad / 64;
   dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
-  if (dv.fam.id == 0 && xpad) {
+  // the scalar-column instantiation addresses a matrix through 32-bit buffer offsets
+  const bool fits32 = (size_t)npad * (size_t)ld * 8 < 0xFFFF0000ull;
+  if (dv.fam.id == 0 && xpad && fits32) {
     hipLaunchKernelGGL(pad_design_kernel, dim3((npad * d + 255) / 256), dim3(256), 0, s, X, n, d, npad, xpad);
     a.colpad = xpad;
     hipLaunchKernelGGL((cov_kernel<0, true>), grid, dim3(256), cov_lds(d, dv.K), s, a);

@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r03/pmc_traffic.json", "r03/pmc_traffic64.json", "r02n/pmc_traffic.json", "r02n/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
+PMC_TRAFFIC_FILES = ("r04/pmc_traffic.json", "r04/pmc_traffic64.json", "r03/pmc_traffic.json", "r03/pmc_traffic64.json", "r02n/pmc_traffic.json", "r02n/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
 
 
 # ----------------------------------------------------------------------------- synthetic inputs

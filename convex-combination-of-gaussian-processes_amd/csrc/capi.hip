@@ -6,8 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <initializer_list>
 #include <map>
+#include <new>
 #include <vector>
 
 #include "ccgp_internal.h"
@@ -28,6 +30,15 @@ namespace {
 
 int fail(ccgp_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg;
+  return code;
+}
+
+// for the catch handlers: assigning the message may itself throw when memory is gone
+int fail_noexcept(ccgp_handle* h, int code, const char* msg) noexcept {
+  try {
+    if (h) h->err = msg;
+  } catch (...) {
+  }
   return code;
 }
 
@@ -432,6 +443,18 @@ __global__ void count_bad_kernel(const int* status, int B, int* out) {
 
 }  // namespace
 
+// No C++ exception may cross the C ABI (inside R that would be std::terminate for the user's session): every entry point
+// that takes a handle is a function-try-block; host-memory exhaustion (std::vector / std::string growth) comes back as
+// CCGP_ENOMEM, anything else as CCGP_EHIP, with the message in ccgp_last_error.
+#define CCGP_GUARD_END(h)                                                                    \
+  catch (const std::bad_alloc&) {                                                            \
+    return fail_noexcept(h, CCGP_ENOMEM, "host memory exhausted inside libccgp");            \
+  } catch (const std::exception& e_) {                                                       \
+    return fail_noexcept(h, CCGP_EHIP, e_.what());                                           \
+  } catch (...) {                                                                            \
+    return fail_noexcept(h, CCGP_EHIP, "unknown C++ exception inside libccgp");              \
+  }
+
 extern "C" {
 
 const char* ccgp_version(void) { return "ccgp-mi355x 0.1 (gfx950)"; }
@@ -442,7 +465,8 @@ int ccgp_create(int device, ccgp_handle** out) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CCGP_EHIP;
   if (hipSetDevice(device) != hipSuccess) return CCGP_EHIP;
-  ccgp_handle* h = new ccgp_handle();
+  ccgp_handle* h = new (std::nothrow) ccgp_handle();
+  if (!h) return CCGP_ENOMEM;
   h->device = device;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -457,7 +481,7 @@ int ccgp_create(int device, ccgp_handle** out) {
   return CCGP_OK;
 }
 
-int ccgp_destroy(ccgp_handle* h) {
+int ccgp_destroy(ccgp_handle* h) try {
   if (!h) return CCGP_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
@@ -473,17 +497,17 @@ int ccgp_destroy(ccgp_handle* h) {
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 const char* ccgp_last_error(const ccgp_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
-int ccgp_set_stream(ccgp_handle* h, void* hip_stream) {
+int ccgp_set_stream(ccgp_handle* h, void* hip_stream) try {
   if (!h) return CCGP_EINVAL;
   h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
-int ccgp_set_kernel(ccgp_handle* h, int family, double nu) {
+int ccgp_set_kernel(ccgp_handle* h, int family, double nu) try {
   if (!h) return CCGP_EINVAL;
   if (family == CCGP_KERNEL_GAUSS) {
     h->fam = ccgp::KernelFamily{};
@@ -495,15 +519,15 @@ int ccgp_set_kernel(ccgp_handle* h, int family, double nu) {
   h->fam.nu = nu;
   h->fam.norm = 1.0 / (std::tgamma(nu) * std::pow(2.0, nu - 1.0));
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
-int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes) {
+int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes) try {
   if (!h || bytes < (size_t(1) << 20)) return CCGP_EINVAL;
   h->ws_limit = bytes;
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
-int ccgp_set_option(ccgp_handle* h, int option, int value) {
+int ccgp_set_option(ccgp_handle* h, int option, int value) try {
   if (!h) return CCGP_EINVAL;
   if (option == CCGP_OPT_UPDATE_STRIPS && (value == 0 || value == 1 || value == 2)) {
     h->opt_strips = value;
@@ -526,15 +550,15 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) {
     return CCGP_OK;
   }
   return fail(h, CCGP_EINVAL, "ccgp_set_option: unknown option or value");
-}
+} CCGP_GUARD_END(h)
 
-int ccgp_synchronize(ccgp_handle* h) {
+int ccgp_synchronize(ccgp_handle* h) try {
   if (!h) return CCGP_EINVAL;
   CCGP_HIP(hipStreamSynchronize(h->stream));
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
-int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m) {
+int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m) try {
   if (!h || bad_shape(n, d, K) || B < 1 || m < 0) return fail(h, CCGP_EINVAL, "ccgp_reserve: bad argument");
   CCGP_HIP(hipSetDevice(h->device));
   if (n > kSmallMaxN || h->fam.id != 0) {
@@ -548,18 +572,18 @@ int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m) {
               Carver::al(sizeof(double) * (size_t)B * P) + 3 * Carver::al(sizeof(double) * B) +
               Carver::al(sizeof(double) * (size_t)m * d) + 2 * Carver::al(sizeof(double) * (size_t)B * m) + 4096;
   return ensure_stage(h, st);
-}
+} CCGP_GUARD_END(h)
 
-int ccgp_enable_timing(ccgp_handle* h, int on) {
+int ccgp_enable_timing(ccgp_handle* h, int on) try {
   if (!h) return CCGP_EINVAL;
   // on = 1: every launch group; otherwise a bit mask, bit (1 + id) selects CCGP_T_<id> (bench.py times only
   // the update launches inside its timed region: two event records per launch are not free)
   h->timing = on == 1 ? ~0u : (unsigned)on >> 1;
   h->spans_used = 0;
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
-int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches) {
+int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches) try {
   if (!h || id < 0 || id >= CCGP_T_COUNT) return CCGP_EINVAL;
   CCGP_HIP(hipStreamSynchronize(h->stream));
   double ms = 0.0;
@@ -574,7 +598,7 @@ int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches) {
   if (out_ms) *out_ms = ms;
   if (out_launches) *out_launches = cnt;
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 // ---- a1-a5 ------------------------------------------------------------------------------
 static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d,
@@ -606,32 +630,32 @@ static int corr_common(ccgp_handle* h, const double* Xnew, int m, const double* 
 }
 
 int ccgp_corr_matrix(ccgp_handle* h, const double* X, int n, int d, const double* theta,
-                     double* out_R) {
+                     double* out_R) try {
   if (!theta || d < 1 || d > kMaxD) return fail(h, CCGP_EINVAL, "ccgp_corr_matrix: bad argument");
   std::vector<double> row(1 + d);
   row[0] = 1.0;
   for (int k = 0; k < d; ++k) row[1 + k] = theta[k];
   return corr_common(h, nullptr, n, X, n, d, 1, row.data(), out_R, true);
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_corr_cross(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d,
-                    const double* theta, double* out) {
+                    const double* theta, double* out) try {
   if (!theta || d < 1 || d > kMaxD) return fail(h, CCGP_EINVAL, "ccgp_corr_cross: bad argument");
   std::vector<double> row(1 + d);
   row[0] = 1.0;
   for (int k = 0; k < d; ++k) row[1 + k] = theta[k];
   return corr_common(h, Xnew, m, X, n, d, 1, row.data(), out, false);
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_mixed_corr_matrix(ccgp_handle* h, const double* X, int n, int d, int K,
-                           const double* params, double* out_R) {
+                           const double* params, double* out_R) try {
   return corr_common(h, nullptr, n, X, n, d, K, params, out_R, true);
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_mixed_corr_cross(ccgp_handle* h, const double* Xnew, int m, const double* X, int n,
-                          int d, int K, const double* params, double* out) {
+                          int d, int K, const double* params, double* out) try {
   return corr_common(h, Xnew, m, X, n, d, K, params, out, false);
-}
+} CCGP_GUARD_END(h)
 
 // ---- a6, a7, a10 ---------------------------------------------------------------------------
 static int rinv_terms(ccgp_handle* h, const double* R_inv, const double* y, int n, double beta,
@@ -653,39 +677,39 @@ static int rinv_terms(ccgp_handle* h, const double* R_inv, const double* y, int 
   return pull(h, {piece(dmf, mean_factor, n), piece(dcs, colsum, n), piece(dsc, scal, 3)});
 }
 
-int ccgp_beta_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double* out_beta) {
+int ccgp_beta_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double* out_beta) try {
   if (!out_beta) return fail(h, CCGP_EINVAL, "ccgp_beta_mle: bad argument");
   double sc[3];
   int rc = rinv_terms(h, R_inv, y, n, 0.0, nullptr, nullptr, sc);
   if (rc) return rc;
   *out_beta = sc[0] / sc[1];
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_sigma2_mle(ccgp_handle* h, const double* R_inv, const double* y, int n, double beta,
-                    double* out_sigma2) {
+                    double* out_sigma2) try {
   if (!out_sigma2) return fail(h, CCGP_EINVAL, "ccgp_sigma2_mle: bad argument");
   double sc[3];
   int rc = rinv_terms(h, R_inv, y, n, beta, nullptr, nullptr, sc);
   if (rc) return rc;
   *out_sigma2 = sc[2] / n;
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_factors(ccgp_handle* h, const double* R_inv, double beta, const double* y, int n,
-                 double* out) {
+                 double* out) try {
   if (!out) return fail(h, CCGP_EINVAL, "ccgp_factors: bad argument");
   double sc[3];
   int rc = rinv_terms(h, R_inv, y, n, beta, out, out + n, sc);
   if (rc) return rc;
   out[2 * n] = sc[1];
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, double beta,
                               const double* mean_factor, const double* var_factor1,
                               double var_factor2, const double* R_inv, double sigma2,
-                              double* out_mean, double* out_var) {
+                              double* out_mean, double* out_var) try {
   if (!h || m < 1 || n < 1 || !r || !mean_factor || !var_factor1 || !R_inv || !out_mean || !out_var)
     return fail(h, CCGP_EINVAL, "ccgp_predict_from_factors: bad argument");
   CCGP_HIP(hipSetDevice(h->device));
@@ -707,12 +731,12 @@ int ccgp_predict_from_factors(ccgp_handle* h, const double* r, int m, int n, dou
                      dv1, var_factor2, dR, sigma2, dmean, dvar);
   CCGP_LAUNCH_CHECK();
   return pull(h, {piece(dmean, out_mean, m), piece(dvar, out_var, m)});
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_predict_post(ccgp_handle* h, const double* Xnew, int m, const double* X, int n, int d, int K,
                       const double* params_row, double beta, const double* mean_factor,
                       const double* var_factor1, double var_factor2, const double* R_inv, double sigma2,
-                      double* out_mean, double* out_var) {
+                      double* out_mean, double* out_var) try {
   if (!h || bad_shape(n, d, K) || m < 1 || !Xnew || !X || !params_row || !mean_factor || !var_factor1 || !R_inv ||
       !out_mean || !out_var)
     return fail(h, CCGP_EINVAL, "ccgp_predict_post: bad argument");
@@ -748,21 +772,21 @@ int ccgp_predict_post(ccgp_handle* h, const double* Xnew, int m, const double* X
                      var_factor2, dR, sigma2, dmean, dvar);
   CCGP_LAUNCH_CHECK();
   return pull(h, {piece(dmean, out_mean, m), piece(dvar, out_var, m)});
-}
+} CCGP_GUARD_END(h)
 
 // ---- a8/a9/a12 -------------------------------------------------------------------------------
 int ccgp_loglik_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy, int K,
                           const double* dparams, int B, double sigma2, int mean_mode, double tau2,
-                          double* d_loglik, double* d_beta, int* d_status) {
+                          double* d_loglik, double* d_beta, int* d_status) try {
   if (!h) return CCGP_EINVAL;
   CCGP_HIP(hipSetDevice(h->device));
   return loglik_dev(h, dX, n, d, dy, K, dparams, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
                     d_status);
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_loglik_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
                       const double* params, int B, double sigma2, int mean_mode, double tau2,
-                      double* out_loglik, double* out_beta, int* status) {
+                      double* out_loglik, double* out_beta, int* status) try {
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || B < 0 || !X || !y || !params || !out_loglik)
     return fail(h, CCGP_EINVAL, "ccgp_loglik_batch: bad argument");
@@ -816,11 +840,11 @@ int ccgp_loglik_batch(ccgp_handle* h, const double* X, int n, int d, const doubl
   }
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
   return count_bad(st.data(), B);
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
                            const double* params, int B, double sigma2, double* out_loglik,
-                           double* out_beta, double* out_grad, int* status) {
+                           double* out_beta, double* out_grad, int* status) try {
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || B < 1 || !X || !y || !params || !out_grad)
     return fail(h, CCGP_EINVAL, "ccgp_loglik_grad_batch: bad argument");
@@ -923,12 +947,12 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
     return prc;
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
   return count_bad(st.data(), B);
-}
+} CCGP_GUARD_END(h)
 
 // ---- a8: logpost ------------------------------------------------------------------------------
 int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2,
                  int prior_id, const double* theta_t, const double* prior_pars, double* out_val,
-                 double* out_beta, double* out_loglik, double* out_Rinv, int* status) {
+                 double* out_beta, double* out_loglik, double* out_Rinv, int* status) try {
   if (!h) return CCGP_EINVAL;
   if (n < 1 || d < 1 || d > kMaxD || !X || !y || !theta_t || !out_val)
     return fail(h, CCGP_EINVAL, "ccgp_logpost: bad argument");
@@ -1062,11 +1086,11 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   if (out_loglik) *out_loglik = ll;
   if (status) *status = st;
   return st != 0 ? 1 : 0;
-}
+} CCGP_GUARD_END(h)
 
 // ---- 8(f)-4: entropy criteria over candidate designs ------------------------------------------------
 int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, int B, int K,
-                              const double* params, double* out_logdet, int* status) {
+                              const double* params, double* out_logdet, int* status) try {
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || B < 1 || !Xs || !params || !out_logdet)
     return fail(h, CCGP_EINVAL, "ccgp_mixed_logdet_designs: bad argument");
@@ -1098,7 +1122,7 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
   if (int prc = pull(h, {piece(dld, out_logdet, B), piece(dst, st.data(), B)})) return prc;
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
   return count_bad(st.data(), B);
-}
+} CCGP_GUARD_END(h)
 
 // ---- a9: hyperprior grid ------------------------------------------------------------------------
 int ccgp_halton_base2(int N, double* out) {
@@ -1115,7 +1139,7 @@ int ccgp_qigamma(const double* p, int N, double alpha, double beta, double* out)
 
 int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const double* y,
                        double sigma2, const double* hyper, int G, int N, double tau, int take_log,
-                       double aniso_lambda, double* out, int* out_argmax, double* out_logs) {
+                       double aniso_lambda, double* out, int* out_argmax, double* out_logs) try {
   if (!h) return CCGP_EINVAL;
   if (n < 1 || d < 1 || d > kMaxD || G < 1 || N < 1 || !X || !y || !hyper || !out)
     return fail(h, CCGP_EINVAL, "ccgp_grid_marginal: bad argument");
@@ -1201,13 +1225,13 @@ int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const doub
     *out_argmax = best;
   }
   return bad;
-}
+} CCGP_GUARD_END(h)
 
 // ---- a10/a11: prediction -------------------------------------------------------------------------
 int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy, int K,
                            const double* dparams, int S, const double* dXtest, int m,
                            double sigma2, double* d_mean, double* d_var, double* d_beta,
-                           int* d_status) {
+                           int* d_status) try {
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || S < 1 || m < 1 || !dX || !dy || !dparams || !dXtest || !d_mean || !d_var)
     return fail(h, CCGP_EINVAL, "ccgp_predict_batch: bad argument");
@@ -1255,11 +1279,11 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   }
   CCGP_LAUNCH_CHECK();
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_predict_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
                        const double* params, int S, const double* Xtest, int m, double sigma2,
-                       double* out_mean, double* out_var, double* out_beta, int* status) {
+                       double* out_mean, double* out_var, double* out_beta, int* status) try {
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || S < 1 || m < 1 || !X || !y || !params || !Xtest || !out_mean || !out_var)
     return fail(h, CCGP_EINVAL, "ccgp_predict_batch: bad argument");
@@ -1291,7 +1315,7 @@ int ccgp_predict_batch(ccgp_handle* h, const double* X, int n, int d, const doub
     return prc;
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)S);
   return count_bad(st.data(), S);
-}
+} CCGP_GUARD_END(h)
 
 // ---- 8(f)-2: device-resident factor set --------------------------------------------------------------
 struct ccgp_factorset {
@@ -1313,7 +1337,7 @@ struct ccgp_factorset {
 
 int ccgp_factor_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, int K,
                       const double* params, int S, double sigma2, ccgp_factorset** out,
-                      double* out_loglik, double* out_beta, int* status) {
+                      double* out_loglik, double* out_beta, int* status) try {
   if (!h) return CCGP_EINVAL;
   if (bad_shape(n, d, K) || S < 1 || !X || !y || !params || !out)
     return fail(h, CCGP_EINVAL, "ccgp_factor_batch: bad argument");
@@ -1384,10 +1408,10 @@ int ccgp_factor_batch(ccgp_handle* h, const double* X, int n, int d, const doubl
   if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)S);
   *out = fs;
   return count_bad(st.data(), S);
-}
+} CCGP_GUARD_END(h)
 
 int ccgp_predict_from_factorset(ccgp_handle* h, const ccgp_factorset* fs, const double* Xtest, int m,
-                                double* out_mean, double* out_var) {
+                                double* out_mean, double* out_var) try {
   if (!h) return CCGP_EINVAL;
   if (!fs || !Xtest || m < 1 || !out_mean || !out_var)
     return fail(h, CCGP_EINVAL, "ccgp_predict_from_factorset: bad argument");
@@ -1449,11 +1473,11 @@ int ccgp_predict_from_factorset(ccgp_handle* h, const ccgp_factorset* fs, const 
   CCGP_HIP(hipMemcpyAsync(out_var, dvar, sizeof(double) * (size_t)S * m, hipMemcpyDeviceToHost, h->stream));
   CCGP_HIP(hipStreamSynchronize(h->stream));
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 size_t ccgp_factorset_bytes(const ccgp_factorset* fs) { return fs ? fs->bytes : 0; }
 
-int ccgp_factorset_free(ccgp_handle* h, ccgp_factorset* fs) {
+int ccgp_factorset_free(ccgp_handle* h, ccgp_factorset* fs) try {
   if (!fs) return CCGP_OK;
   if (h) {
     (void)hipSetDevice(h->device);
@@ -1462,6 +1486,6 @@ int ccgp_factorset_free(ccgp_handle* h, ccgp_factorset* fs) {
   if (fs->mem) (void)hipFree(fs->mem);
   delete fs;
   return CCGP_OK;
-}
+} CCGP_GUARD_END(h)
 
 }  // extern "C"

@@ -1202,7 +1202,11 @@ int ccgp_grid_marginal(ccgp_handle* h, const double* X, int n, int d, const doub
   CCGP_HIP(hipMemsetAsync(dbad, 0, sizeof(int), h->stream));
   {
     ScopedTimer t(h, CCGP_T_COV);
-    hipLaunchKernelGGL(grid_qtab_kernel, dim3((unsigned)((ns * N + 255) / 256)), dim3(256), 0, h->stream, dsh, (int)ns, N, dq);
+    // ns x N quantiles (a dozen shapes x 1000 nodes: ~12 000 threads, each a long serial Halley iteration) cannot fill
+    // the chip; what matters is each wave's own speed.  One wave per workgroup spreads them over ~190 CUs where a lone
+    // wave issues every 7.5 cycles, against one instruction per ~19 cycles when four waves share a SIMD
+    // (profiles/r04/valu_f64_rates.txt): 1.96 -> 1.17 ms of the Heat-Exchanger grid's 11 ms end to end (and 0.08 once the quantile iteration stops at rounding level: special_math.h)
+    hipLaunchKernelGGL(grid_qtab_kernel, dim3((unsigned)((ns * N + 63) / 64)), dim3(64), 0, h->stream, dsh, (int)ns, N, dq);
     hipLaunchKernelGGL(grid_expand_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, dhy, dsi, dq, G, N,
                        d, aniso ? 1 : 0, aniso_lambda, dp);
   }

@@ -280,6 +280,23 @@ def cpu_logpost_latency(X, y, sigma2, calls=200):
     return {"us_per_call": 1e6 * el, "unit": "us per oracle.logpost call (numpy, reference operation sequence)", "calls": calls}
 
 
+def cpu_predict_post_latency(X, y, x_new, sigma2, calls=200):
+    """One literal predict.post call on the CPU with the cached terms given (HX:655-673: r = Mixed.corr.vec, then the
+    arithmetic with the frame row's R.Inv): the oracle's numpy restatement, one call at a time as `apply` makes them."""
+    from oracle import ccgp_oracle as orc
+    n, d = X.shape
+    R = orc.mixed_corr_matrix_iso(X, 0.7, 0.3, 15.0)
+    R_inv = orc.solve_inverse(R)
+    beta = orc.beta_mle(R_inv, y)
+    mf, v1, v2 = orc.factors(R_inv, beta, y)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        r = orc.mixed_corr_vec_iso(x_new, X, 0.7, 0.3, 15.0)
+        orc.predict_post_from_factors(r, beta, mf, v1, v2, R_inv, sigma2)
+    return {"us_per_call": 1e6 * (time.perf_counter() - t0) / calls, "cores": 1, "calls": calls,
+            "what": "numpy restatement of one R-level predict.post call (oracle/ccgp_oracle.py), cached terms given"}
+
+
 def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2):
     big = X.shape[0] > 1000
     c = cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core=2 if big else 2000, one_core_evals=2 if big else 4000)
@@ -475,6 +492,9 @@ def run_loglik_workload(c):
             cpu_sec["cfg5"] = cpu_predict_sample(*sec_in["cfg5"])
             cpu_sec["logpost"] = cpu_logpost_latency(X2, y2, s22)
             cpu_sec["gradient"], cpu_sec["gradient_fd"] = cpu_gradient_fd(X2, y2, P2, K2, s22)
+            gvX, gvy, gvXt = sec_in["cfg5"][0][-1]
+            cpu_sec["predict_post"] = {"Qian n=64": cpu_predict_post_latency(X2, y2, X2[0] * 0.97, 10.0),
+                                       "GV n=%d" % gvX.shape[0]: cpu_predict_post_latency(gvX, gvy, gvXt[0], 10.0)}
             if args.n == 4096:
                 cpu_sec["cfg4_predict"] = cpu_predict_n4096(X, y, K, P[:CFG4_PREDICT_DRAWS], sigma2)
 
@@ -763,7 +783,7 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
                   "per_design": lit, "calls": calls,
                   "batched_ns_per_prediction_kernel": 1e9 * el5 / pairs, "batched_ns_per_prediction_end_to_end": 1e9 * e2e5 / pairs,
                   "test_set_of_1000x150_literal_s": 1e-6 * lit[-1]["us_per_predict_post_one_call"] * 150000,
-                  "test_set_of_1000x150_batched_ms": 1e3 * e2e5 / len(sets), "cpu": None})
+                  "test_set_of_1000x150_batched_ms": 1e3 * e2e5 / len(sets), "cpu": cpu_sec.get("predict_post")})
     # the north_star's "+ gradient": ccgp_loglik_grad_batch (host pointers) on the Heat-Exchanger design, next to the
     # same call without the gradient
     Bg = 65536

@@ -291,7 +291,17 @@ static int frame_rows(SEXP f) {
   if (TYPEOF(f) == VECSXP) return Rf_length(f) > 0 ? Rf_length(VECTOR_ELT(f, 0)) : 0;
   return Rf_nrows(f);
 }
-static int frame_cols(SEXP f) { return TYPEOF(f) == VECSXP ? Rf_length(f) : Rf_ncols(f); }
+/* the leading `need` columns are numeric and as long as the first one (a list that is not a data frame may hold anything) */
+static int frame_ok(SEXP f, int need) {
+  if (TYPEOF(f) == REALSXP || TYPEOF(f) == INTSXP) return Rf_ncols(f) >= need;
+  if (TYPEOF(f) != VECSXP || Rf_length(f) < need) return 0;
+  const int S = Rf_length(VECTOR_ELT(f, 0));
+  for (int j = 0; j < need; ++j) {
+    SEXP col = VECTOR_ELT(f, j);
+    if ((TYPEOF(col) != REALSXP && TYPEOF(col) != INTSXP) || Rf_length(col) != S) return 0;
+  }
+  return 1;
+}
 static double frame_get(SEXP f, int s, int j, int S) {
   SEXP col = f;
   R_xlen_t at = (R_xlen_t)s + (R_xlen_t)j * S;
@@ -327,7 +337,7 @@ static int table_into(SEXP frame, SEXP Dtrain, SEXP Dtest, SEXP sigma2, SEXP ytr
                       SEXP params, double* mean, double* var, double* beta) {
   const int n = Rf_nrows(Dtrain), d = Rf_ncols(Dtrain), m = Rf_nrows(Dtest), S = frame_rows(frame);
   const int need = layout == LAYOUT_ANI ? 4 : 3;
-  if (!layout_ok(layout, d) || layout == LAYOUT_ADV_WRITTEN || S < 1 || m < 1 || frame_cols(frame) < need ||
+  if (!layout_ok(layout, d) || layout == LAYOUT_ADV_WRITTEN || S < 1 || m < 1 || !frame_ok(frame, need) ||
       Rf_ncols(Dtest) != d || Rf_length(ytrain) != n) {
     Rf_warning("libccgp: prediction table: frame / design shapes do not fit layout %d", layout);
     return CCGP_EINVAL;

@@ -225,6 +225,12 @@ def test_prediction_table_from_a_factors_frame_is_predict_batch_bit_for_bit(R, h
     got = R.dot_call("ccgp_R_prediction_table", *args(R.real(bad)))
     assert R.is_na(got[0][2]).all() and R.is_na(got[1][2]).all() and not R.is_na(got[0][[0, 1, 3, 4, 5]]).any()
     assert np.array_equal(got[0][[0, 1, 3, 4, 5]], mean[[0, 1, 3, 4, 5]])
+    # a list whose columns are not equally long is not a frame: warning + NA (no read past the short column)
+    ragged = R.frame(frame[:, :3])
+    R.L.rmock_list_set(ragged, 2, R.real(frame[:2, 2]))
+    got = R.dot_call("ccgp_R_prediction_table", *args(ragged))
+    assert R.is_na(got[0]).all() and "do not fit layout" in R.warnings()[-1]
+    R.reset()
     # shapes that do not fit the layout: warning + NA, never an error
     got = R.dot_call("ccgp_R_prediction_table", R.real(frame[:, :2]), R.real(D), R.real(Dt), R.real(10.0), R.real(y),
                      R.integer(0), R.real(0.0))

@@ -72,3 +72,65 @@ def test_r_overrides_coerce_every_call_argument():
     rsrc = open(os.path.join(ROOT, "r", "ccgp.R")).read()
     assert ".ccgp.mat <- function" in rsrc
     assert "as.matrix(" not in rsrc.replace(".ccgp.mat <- function(x) { x <- as.matrix(x)", "")
+
+
+def _strip_r_comments_and_strings(src):
+    """R source with comments removed and string literals blanked (their quotes kept), for bracket / call scanning."""
+    out, i, n, quote = [], 0, len(src), None
+    while i < n:
+        c = src[i]
+        if quote:
+            if c == "\\":
+                out.append("  ")
+                i += 2
+                continue
+            out.append(c if c == quote else " ")
+            if c == quote:
+                quote = None
+        elif c == "#":
+            while i < n and src[i] != "\n":
+                i += 1
+            continue
+        else:
+            if c in "\"'":
+                quote = c
+            out.append(c)
+        i += 1
+    return "".join(out), quote
+
+
+def test_r_overrides_call_registered_routines_with_the_registered_arity():
+    """r/ccgp.R cannot run here (no R).  What can be checked statically: its brackets balance, and every
+    .Call("ccgp_R_*", ...) names a routine that r/ccgp_shim.c registers and passes exactly the registered number of
+    arguments (R would stop with "Incorrect number of arguments" at run time)."""
+    raw = open(os.path.join(ROOT, "r", "ccgp.R")).read()
+    shim = open(os.path.join(ROOT, "r", "ccgp_shim.c")).read()
+    table = dict((n, int(k)) for n, k in re.findall(r'\{"(ccgp_R_\w+)", \(DL_FUNC\)&\w+, (\d+)\}', shim))
+    src, open_quote = _strip_r_comments_and_strings(raw)
+    assert open_quote is None
+    stack, pairs = [], {")": "(", "}": "{", "]": "["}
+    for k, c in enumerate(src):
+        if c in "({[":
+            stack.append(c)
+        elif c in ")}]":
+            assert stack and stack.pop() == pairs[c], "unbalanced %r near line %d" % (c, src[:k].count("\n") + 1)
+    assert not stack
+    sites = 0
+    for m in re.finditer(r'\.Call\("(ccgp_R_\w+)"', raw):
+        name = m.group(1)
+        line = raw[:m.start()].count("\n") + 1
+        assert name in table, "%s (line %d) is not registered" % (name, line)
+        # the same offsets hold in `src` (strings are blanked in place, comments removed only AFTER this call's line
+        # start in the cases below, so re-find the call in the stripped text)
+        sm = [x for x in re.finditer(r'\.Call\("', src) if src[:x.start()].count("\n") + 1 == line]
+        assert sm, line
+        p, depth, commas = src.index("(", sm[0].start()) + 1, 1, 0
+        while depth:
+            ch = src[p]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            commas += ch == "," and depth == 1
+            p += 1
+        assert commas == table[name], "%s at line %d passes %d arguments, %d registered" % (name, line, commas, table[name])
+        sites += 1
+    assert sites >= 30

@@ -268,7 +268,7 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
     ScopedTimer t(h, CCGP_T_FUSED);
     if (reg_ok)
       launch_small_reg_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
-                              d_status);
+                              d_status, h->opt_small_grid16 != 0);
     else
       launch_small_loglik(h->stream, dX, n, d, dy, dv, B, sigma2, mean_mode, tau2, d_loglik, d_beta,
                           d_status);
@@ -547,6 +547,10 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
   }
   if (option == CCGP_OPT_WIDE_OFFSETS && (value == 0 || value == 1)) {
     h->opt_wide_offsets = value;
+    return CCGP_OK;
+  }
+  if (option == CCGP_OPT_SMALL_GRID16 && (value == 0 || value == 1)) {
+    h->opt_small_grid16 = value;
     return CCGP_OK;
   }
   return fail(h, CCGP_EINVAL, "ccgp_set_option: unknown option or value");

@@ -68,6 +68,7 @@ struct ccgp_handle {
   size_t ws_limit = size_t(24) << 30;   // ccgp_create replaces this by 3/4 of the device's memory
   int opt_strips = 0;                   // CCGP_OPT_UPDATE_STRIPS
   int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
+  int opt_small_grid16 = 0;             // CCGP_OPT_SMALL_GRID16
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
   int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
@@ -150,7 +151,7 @@ void launch_small_reg_grad(hipStream_t s, const double* X, int n, int d, const d
                            double sigma2, double* loglik, double* beta, double* grad, int* status);
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                              int B, double sigma2, int mean_mode, double tau2, double* loglik,
-                             double* beta, int* status);
+                             double* beta, int* status, bool grid16 = false);
 
 // ---- blocked.hip ---------------------------------------------------------------------
 struct BlockedWs {

@@ -24,7 +24,6 @@
 //
 // Bound: neither HBM nor MFMA -- n dependent elimination steps; algorithmic HBM traffic per
 // evaluation is the parameter row in (8 P bytes) and 20 bytes out.
-#include <cstdlib>
 #include <type_traits>
 
 #include "ccgp_internal.h"
@@ -59,6 +58,7 @@ struct RegArgs {
   double* Rinv;        // INV = 1: n x n explicit inverse of the (normalised) mixed correlation matrix
   double* grad;        // INV = 2: d loglik / d params, Btot x P column-major (element (b, j) at grad[b + j * Btot])
   int Btot;
+  int grid16;          // CCGP_OPT_SMALL_GRID16: 64 < n <= 104 on the 16 x 16 grid (measurements)
 };
 
 // doubles of LDS per matrix, from the ACTUAL number of components and dimensions (round 3: sized for kMaxK / kMaxD
@@ -706,11 +706,11 @@ static void dispatch(hipStream_t s, const RegArgs& a);
 
 void launch_small_reg_loglik(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                              int B, double sigma2, int mean_mode, double tau2, double* loglik,
-                             double* beta, int* status) {
+                             double* beta, int* status, bool grid16) {
   RegArgs a{};
   a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
   a.draw0 = 0; a.B = B; a.sigma2 = sigma2; a.mode = mean_mode; a.tau2 = tau2;
-  a.loglik = loglik; a.beta = beta; a.status = status;
+  a.loglik = loglik; a.beta = beta; a.status = status; a.grid16 = grid16;
   dispatch(s, a);
 }
 
@@ -750,11 +750,11 @@ static void dispatch(hipStream_t s, const RegArgs& a) {
     // blocks per thread (two waves per SIMD: up to 256 VGPRs) -- at n = 100 1.68 x the minimal FMAs instead of the
     // 2.75 x of the 16 x 16 grid at NB = 7, no s_barrier, and the per-column overhead (pivot, reciprocal, column
     // broadcast) is paid by one wave instead of four: 25.7 k -> ~10 k VALU instructions per evaluation, 6.06 -> 5.07 ms
-    // per 103 680 evaluations on the same box, same bits (profiles/r04).  CCGP_NO_G8_WIDE=1: the 16 x 16 grid (A/B).
+    // per 103 680 evaluations on the same box, same bits (profiles/r04).  CCGP_OPT_SMALL_GRID16: the 16 x 16 grid (A/B).
     const int nb8 = (n + 7) / 8;
     const bool fits8 = sizeof(double) * (kSmallExpTable + (size_t)a.d * n + (size_t)4 * kPerMat(8 * nb8, 8, 1, a.K, a.d) +
                                          (a.x_stride ? (size_t)4 * a.d * n : 0)) <= (size_t)kLdsBytes - 64;   // four matrices per workgroup
-    if (n > 64 && n <= 104 && !wide && fits8 && getenv("CCGP_NO_G8_WIDE") == nullptr) {
+    if (n > 64 && n <= 104 && !wide && fits8 && !a.grid16) {
       switch ((n + 7) / 8) {
         case 9: launch_one<8, 9, NE>(s, a); break;
         case 10: launch_one<8, 10, NE>(s, a); break;

@@ -103,9 +103,11 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           as two half-width strips each; 0 = every tile whole
  *   CCGP_OPT_WIDE_OFFSETS   0 (default) = the update loops address their panels through 32-bit buffer offsets wherever a
  *                           panel spans less than 4 GiB; 1 = always the 64-bit-pointer loops that larger matrices
- *                           fall back to (same bits: the tests hold one against the other) */
+ *                           fall back to (same bits: the tests hold one against the other)
+ *   CCGP_OPT_SMALL_GRID16   0 (default) = 64 < n <= 104 runs ONE wave per matrix on the 8 x 8 thread grid (up to 13 x 13
+ *                           blocks per thread); 1 = the 16 x 16 grid (one workgroup per matrix) of rounds 1 - 3 (same bits) */
 enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3,
-       CCGP_OPT_WIDE_OFFSETS = 4 };
+       CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5 };
 int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);

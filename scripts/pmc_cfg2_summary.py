@@ -5,7 +5,7 @@ busy fractions.  SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles (M
 import collections, csv, json, sys
 tag = sys.argv[1]
 wl = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'      # cfg2 (n = 64: one wave per evaluation) | cfg3 (n = 100)
-# cfg3: one workgroup of 4 waves per evaluation on the 16 x 16 grid (rounds 1 - 3, CCGP_NO_G8_WIDE=1), ONE wave per
+# cfg3: one workgroup of 4 waves per evaluation on the 16 x 16 grid (rounds 1 - 3, CCGP_OPT_SMALL_GRID16 / bench.py --small-grid16), ONE wave per
 # evaluation on the 8 x 8 grid with 13 x 13 blocks per thread (round 4); pass 4 as third argument for the former
 waves_per_eval = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 tot = collections.defaultdict(float)

@@ -14,7 +14,7 @@ tail -c 300 $OUT/bench_default.json; echo
 python3 $R/bench.py --evals-total 64 --steps 10 --no-cpu-baseline --no-secondary > $OUT/bench_slice64.json 2> $OUT/bench_slice64.err
 python3 $R/bench.py --workload cfg2 --steps 10 --warmup 2 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 python3 $R/bench.py --workload cfg3 --steps 10 --warmup 2 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
-CCGP_NO_G8_WIDE=1 python3 $R/bench.py --workload cfg3 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg3_grid16.json 2> $OUT/bench_cfg3_grid16.err
+python3 $R/bench.py --workload cfg3 --small-grid16 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg3_grid16.json 2> $OUT/bench_cfg3_grid16.err
 python3 $R/bench.py --workload cfg5 --steps 10 --warmup 2 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
 $R/tests/hip/valu_rates > $OUT/valu_f64_rates.txt 2>&1
 $R/tests/hip/mfma_valu_overlap > $OUT/mfma_valu_overlap.txt 2>&1

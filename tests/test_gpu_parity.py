@@ -956,3 +956,32 @@ def test_widest_design_and_largest_chunks(handle):
         handle.set_option(99, 1)
     with pytest.raises(api.CcgpError):
         handle.set_option(api.OPT_UPDATE_STRIPS, 3)
+
+
+@pytest.mark.parametrize("n", [65, 72, 81, 96, 100, 104])
+def test_one_wave_per_matrix_and_the_16x16_grid_give_the_same_bits(handle, n):
+    """64 < n <= 104 runs one wave per matrix on the 8 x 8 thread grid (up to 13 x 13 blocks per thread) since round 4;
+    OPT_SMALL_GRID16 selects the 16 x 16 grid of rounds 1 - 3.  Every matrix entry sees the same operations in the same
+    order on both, so log-likelihood, beta and status must agree bit for bit -- in both mean modes, including a draw whose
+    factorisation fails -- and both must agree with the oracle."""
+    from ccgp_amd import api
+    d, K = 2, 2
+    X, y = synthetic_design(n, d, seed=7 * n)
+    rng = np.random.default_rng(n)
+    B = 70                                          # more than 64 draws: the throughput dispatch, not the latency one
+    P = np.column_stack([rng.uniform(0.3, 0.9, B), rng.uniform(0.1, 0.7, B), rng.uniform(0.5, 3.0, (B, d)),
+                         rng.uniform(20.0, 60.0, (B, d))])
+    P[5, 2:] = 0.0                                  # R = 11': singular
+    for mode, tau2 in ((api.MEAN_PROFILE_BETA, 0.0), (api.MEAN_ZERO_PLUS_TAU2, 9.0)):
+        a = handle.loglik_batch(X, y, K, P, 1.3, mode, tau2)
+        handle.set_option(api.OPT_SMALL_GRID16, 1)
+        try:
+            b = handle.loglik_batch(X, y, K, P, 1.3, mode, tau2)
+        finally:
+            handle.set_option(api.OPT_SMALL_GRID16, 0)
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+        assert a[2][5] != 0 and np.isnan(a[0][5]) and (np.delete(a[2], 5) == 0).all()
+        w, Th = orc.unpack_params(P[0], K, d)
+        want = orc.loglik_general(X, y, w, Th, 1.3, mode, tau2)[0]
+        assert a[0][0] == pytest.approx(want, rel=1e-9)

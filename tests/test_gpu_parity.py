@@ -985,3 +985,24 @@ def test_one_wave_per_matrix_and_the_16x16_grid_give_the_same_bits(handle, n):
         w, Th = orc.unpack_params(P[0], K, d)
         want = orc.loglik_general(X, y, w, Th, 1.3, mode, tau2)[0]
         assert a[0][0] == pytest.approx(want, rel=1e-9)
+
+
+def test_large_tables_come_back_in_slices_unchanged(handle):
+    """Host-pointer ccgp_predict_batch with 2 x 840 KB of tables: the results cross PCIe in four slices, each copied out of
+    the pinned buffer while the next is on its way (capi.hip: pull).  Every piece (mean, var, beta, status) straddles slice
+    boundaries somewhere.  The same draws in chunks of 100 (240 KB per call: one slice) must give the same bits -- every
+    draw is computed by its own workgroup, so only the way back differs."""
+    D, y, Dt, _ = load_gv(50)
+    rng = np.random.default_rng(17)
+    S = 700
+    P = np.array([np.concatenate([[p, 1 - p], np.full(9, a), np.full(9, b)]) for p, a, b in
+                  zip(rng.uniform(0.5, 0.9, S), rng.uniform(0.2, 0.5, S), rng.uniform(10, 20, S))])
+    P[123, 2:] = 0.0                                   # one failing draw: NaN row, status != 0
+    mean, var, beta, st = handle.predict_batch(D, y, 2, P, Dt, 10.0)
+    for lo in range(0, S, 100):
+        m2, v2, b2, s2 = handle.predict_batch(D, y, 2, P[lo:lo + 100], Dt, 10.0)
+        np.testing.assert_array_equal(mean[lo:lo + 100], m2)
+        np.testing.assert_array_equal(var[lo:lo + 100], v2)
+        np.testing.assert_array_equal(beta[lo:lo + 100], b2)
+        np.testing.assert_array_equal(st[lo:lo + 100], s2)
+    assert st[123] != 0 and np.isnan(mean[123]).all() and np.isfinite(np.delete(mean, 123, axis=0)).all()

@@ -50,6 +50,10 @@ def load_hyper(which):
 @pytest.fixture(scope="session")
 def handle():
     """A libccgp handle on GPU 0 -- only requested by gpu-marked tests."""
+    try:
+        import torch  # noqa: F401  (a test that also uses torch needs it loaded BEFORE libccgp: INTEGRATION.md section 5)
+    except ImportError:
+        pass
     from ccgp_amd import api
     h = api.Handle(0)
     yield h

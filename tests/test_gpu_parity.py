@@ -1006,3 +1006,39 @@ def test_large_tables_come_back_in_slices_unchanged(handle):
         np.testing.assert_array_equal(beta[lo:lo + 100], b2)
         np.testing.assert_array_equal(st[lo:lo + 100], s2)
     assert st[123] != 0 and np.isnan(mean[123]).all() and np.isfinite(np.delete(mean, 123, axis=0)).all()
+
+
+def test_one_wave_per_matrix_random_shapes_against_the_oracle(handle):
+    """Random (n, d, K) in the range the one-wave 8 x 8 grid serves (64 < n <= 104), including K = 3 and wide designs
+    (d = 20: still four matrices per workgroup in LDS; d = 40: falls back to the 16 x 16 grid): the 16 x 16 grid gives
+    the same bits, the oracle the same numbers."""
+    from ccgp_amd import api
+    rng = np.random.default_rng(2024)
+    for trial in range(10):
+        n = int(rng.integers(65, 105))
+        d = int(rng.choice([1, 2, 3, 5, 9, 20, 40]))
+        K = int(rng.choice([1, 2, 3]))
+        X, y = synthetic_design(n, d, seed=100 + trial)
+        B = 66
+        W = rng.uniform(0.3, 0.9, (B, K))
+        rough = 2.0 * n ** (2.0 / d) / d                      # theta h^2 ~ 1 at the typical spacing h = n^(-1/d)
+        Th = np.exp(rng.uniform(np.log(0.01 * rough), np.log(0.3 * rough), (B, K * d)))
+        Th[:, -d:] = rng.uniform(rough, 2.0 * rough, (B, d))   # the roughest component keeps R positive definite
+        P = np.column_stack([W, Th])
+        mode, tau2 = ((api.MEAN_PROFILE_BETA, 0.0), (api.MEAN_ZERO_PLUS_TAU2, 4.0))[trial % 2]
+        a = handle.loglik_batch(X, y, K, P, 0.9, mode, tau2)
+        handle.set_option(api.OPT_SMALL_GRID16, 1)
+        try:
+            b = handle.loglik_batch(X, y, K, P, 0.9, mode, tau2)
+        finally:
+            handle.set_option(api.OPT_SMALL_GRID16, 0)
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v, err_msg="n=%d d=%d K=%d" % (n, d, K))
+        assert (a[2] == 0).sum() >= B - 3, (n, d, K, a[2])     # a numerically singular draw may occur; it must be rare
+        for bidx in [i for i in (0, B - 1) if a[2][i] == 0]:
+            w, T = orc.unpack_params(P[bidx], K, d)
+            want_ll, want_beta = orc.loglik_general(X, y, w, T, 0.9, mode, tau2)
+            cond = np.linalg.cond(orc.mixed_corr_matrix_general(X, w, T))
+            assert a[0][bidx] == pytest.approx(want_ll, rel=max(1e-10, 20 * cond * np.finfo(float).eps)), (n, d, K, cond)
+            if mode == api.MEAN_PROFILE_BETA:
+                assert a[1][bidx] == pytest.approx(want_beta, rel=max(1e-9, 50 * cond * np.finfo(float).eps), abs=1e-10)

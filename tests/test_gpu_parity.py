@@ -1042,3 +1042,23 @@ def test_one_wave_per_matrix_random_shapes_against_the_oracle(handle):
             assert a[0][bidx] == pytest.approx(want_ll, rel=max(1e-10, 20 * cond * np.finfo(float).eps)), (n, d, K, cond)
             if mode == api.MEAN_PROFILE_BETA:
                 assert a[1][bidx] == pytest.approx(want_beta, rel=max(1e-9, 50 * cond * np.finfo(float).eps), abs=1e-10)
+
+
+@pytest.mark.parametrize("n,d,K", [(30, 5, 3), (50, 8, 4), (100, 3, 7), (20, 1, 2), (77, 9, 2)])
+def test_small_n_gradient_pass_structure(handle, n, d, K):
+    """The round-4 gradient contraction carries QG x KG accumulators per pass over the pairs: 3 components x 8 dimensions
+    when d <= 8 (K = 3, d = 5: one pass; K = 4, d = 8 and K = 7, d = 3: several component groups), 1 x 16 otherwise
+    (d = 9).  Every case against central differences of the oracle's log-likelihood."""
+    X, y = synthetic_design(n, d, seed=11 * n + d)
+    rng = np.random.default_rng(n + K)
+    rough = 2.0 * n ** (2.0 / d) / d
+    W = rng.uniform(0.3, 0.9, K)
+    Th = np.exp(rng.uniform(np.log(0.02 * rough), np.log(0.3 * rough), (K, d)))
+    Th[-1] = rng.uniform(rough, 2.0 * rough, d)
+    row = np.concatenate([W, Th.ravel()])
+    ll, beta, grad, st = handle.loglik_grad_batch(X, y, K, np.stack([row, row * 1.01]), 0.8)
+    assert not st.any() and np.isfinite(grad).all()
+    w, T = orc.unpack_params(row, K, d)
+    assert ll[0] == pytest.approx(orc.loglik_general(X, y, w, T, 0.8)[0], rel=1e-9)
+    fd = orc.loglik_grad_fd(X, y, row, K, d, 0.8)
+    np.testing.assert_allclose(grad[0], fd, rtol=5e-5, atol=5e-5 * np.abs(fd).max())

@@ -35,6 +35,7 @@
 // We feed A := Q (the block-column operand) and B := P (the block-row operand), so D's
 // lane index runs along matrix ROWS: a wave's store is 4 columns x 128 contiguous bytes.
 #include <cstdlib>
+#include <vector>
 
 #include "ccgp_internal.h"
 
@@ -73,6 +74,15 @@ struct GemmArgs {
   int* status;
   int n;
   double ptol;   // pivot_tolerance(mean_mode, n) for the fused diagonal factorisation
+  // round 4: whole update tiles that lie inside the matrix proper GENERATE their covariance tile instead of reading it
+  // (update_tile_il_gen); cov_kernel then writes only block column 0, the diagonal tiles, the edge row and the block
+  // columns whose launch has a tail of ring strips
+  int fuse_gen;
+  const double* xpad;     // design zero-padded to npad rows, npad x d
+  const double* upad;     // u[z][c][i], nb x K x npad (cov_u_kernel)
+  const double* params;   // draws, column-major with leading dimension ldp
+  int ldp, K, d, draw0, mean_mode;
+  double sigma2, tau2;
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
@@ -365,6 +375,119 @@ __device__ __forceinline__ void update_tile_il(double* smem, const double* P, in
       *(d4*)(Cl + (size_t)(16 * r + x) * ld) = o;
     }
   }
+}
+
+// LDS of the generating epilogue (doubles), laid over the k-loop's stage images once they are free:
+//   etab[256] | xs[K][d][128] (row coordinates times theta) | xc[d][128] | ur[K][128] | uc[K][128] | w2[K]
+__host__ __device__ inline size_t gen_lds_doubles(int d, int K) {
+  return (size_t)kExpTableDoubles + (size_t)K * d * kTile + (size_t)d * kTile + (size_t)2 * K * kTile + K;
+}
+
+// Whole update tile whose covariance tile is GENERATED here instead of being read: T = R_tile - acc.  Round 3's review
+// asked for it (five HBM passes over the matrix: cov write, update read + write, trsm read + write); what it costs was
+// measured first in the real kernel (profiles/r04_experiments.md section 13: a tile's worth of fp64 vector instructions
+// in this epilogue costs 6.9 ms per 512-matrix sweep, half of their issue time hides in the 8 % of SIMD time the MFMA
+// stream leaves open) against 13 ms of cov_kernel.  Same arithmetic, operand values and order as cov_kernel
+// (cov_mix_term; u from cov_u_kernel; scale and shift formed the same way), so the bits of a tile do not depend on who
+// produced it.  Lane = 4 consecutive rows x 16 columns (acc[x][y] register r = row0 + 4 l15 + y, col0 + 16 r + 4 l4 + x):
+// per column group r two 2 x 4 micro-tiles whose row and column coordinates come as ds_read_b128.
+__device__ __forceinline__ void update_tile_il_gen(double* smem, const double* P, int ldP, const double* Q, int ldQ,
+                                                   int Kdim, double* C, int ld, const GemmArgs& g, int b, int i) {
+  d4 acc[4][4];
+  tile_accumulate_il(smem, P, ldP, Q, ldQ, Kdim, acc);
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int d = g.d, K = g.K, tid = threadIdx.x;
+  double* etab = smem;
+  double* xs = etab + kExpTableDoubles;      // [K][d][128]
+  double* xc = xs + (size_t)K * d * kTile;   // [d][128]
+  double* ur = xc + (size_t)d * kTile;       // [K][128]
+  double* uc = ur + (size_t)K * kTile;       // [K][128]
+  double* w2 = uc + (size_t)K * kTile;       // [K]
+  const int I0 = i * kTile, J0 = g.j * kTile, gb = g.draw0 + b;
+  __syncthreads();   // every wave has read its last fragments: the stage images are free
+  exp_table_load(etab, tid, 256);
+  for (int e = tid; e < K * d * kTile; e += 256) {
+    const int r = e & (kTile - 1), ck = e >> 7, k = ck % d;
+    xs[e] = g.xpad[I0 + r + (size_t)k * g.npad] * g.params[gb + (size_t)(K + ck) * g.ldp];
+  }
+  for (int e = tid; e < d * kTile; e += 256) xc[e] = g.xpad[J0 + (e & (kTile - 1)) + (size_t)(e >> 7) * g.npad];
+  const double* ub = g.upad + (size_t)b * K * g.npad;
+  for (int e = tid; e < K * kTile; e += 256) {
+    ur[e] = ub[(size_t)(e >> 7) * g.npad + I0 + (e & (kTile - 1))];
+    uc[e] = ub[(size_t)(e >> 7) * g.npad + J0 + (e & (kTile - 1))];
+  }
+  if (tid < K) {
+    const double w = g.params[gb + (size_t)tid * g.ldp];
+    w2[tid] = w * w;
+  }
+  __syncthreads();
+  double sw = 0.0;
+  for (int c = 0; c < K; ++c) sw += w2[c];
+  const double post_scale = g.mean_mode == 1 ? g.sigma2 * sw : 1.0;
+  const double post_shift = g.mean_mode == 1 ? g.tau2 : 0.0;
+  const double inv_sw = 1.0 / sw;
+  const double scale = post_scale * inv_sw;
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 64;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int rl = row0 + 4 * l15;             // this lane's four rows rl .. rl + 3
+  constexpr int RY = 2;                      // rows of a micro-tile: 2 x 4 keeps sd + mix at 32 VGPRs beside the 128 of acc (4 x 4 spilled 280 B)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int cl = col0 + 16 * r + 4 * l4;   // and four columns cl .. cl + 3 of column group r
+#pragma unroll
+    for (int y0 = 0; y0 < 4; y0 += RY) {
+      double mix[RY][4];                     // [y][x]
+#pragma unroll
+      for (int y = 0; y < RY; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) mix[y][x] = 0.0;
+      for (int c = 0; c < K; ++c) {
+        double sd[RY][4];
+#pragma unroll
+        for (int y = 0; y < RY; ++y)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) sd[y][x] = 0.0;
+        const double* xsc = xs + (size_t)c * d * kTile + rl + y0;
+        for (int k = 0; k < d; ++k) {
+          const d2 ra = *(const d2*)(xsc + k * kTile);
+          const d2 ca = *(const d2*)(xc + k * kTile + cl), cb = *(const d2*)(xc + k * kTile + cl + 2);
+          const double rv[2] = {ra[0], ra[1]}, cv[4] = {ca[0], ca[1], cb[0], cb[1]};
+#pragma unroll
+          for (int y = 0; y < RY; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) sd[y][x] = fma(rv[y], cv[x], sd[y][x]);
+        }
+        const d2 ua = *(const d2*)(ur + c * kTile + rl + y0);
+        const d2 va = *(const d2*)(uc + c * kTile + cl), vb = *(const d2*)(uc + c * kTile + cl + 2);
+        const double uv[2] = {ua[0], ua[1]}, vv[4] = {va[0], va[1], vb[0], vb[1]};
+        const double wc = w2[c];
+#pragma unroll
+        for (int y = 0; y < RY; ++y) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) mix[y][x] = cov_mix_term(mix[y][x], wc, uv[y], vv[x], sd[y][x], etab);
+          // four exp chains in flight, not eight: with the 128 accumulator registers live the scheduler's appetite for
+          // parallel chains otherwise ends in scratch (200 B per lane)
+          asm volatile("" : "+v"(mix[y][0]), "+v"(mix[y][1]), "+v"(mix[y][2]), "+v"(mix[y][3]));
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < RY; ++y) acc[x][y0 + y][r] = fma(scale, mix[y][x], post_shift) - acc[x][y0 + y][r];
+    }
+  }
+  double* Cl = C + row0 + 4 * l15 + (size_t)(col0 + 4 * l4) * ld;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d4 o;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) o[y] = acc[x][y][r];
+      *(d4*)(Cl + (size_t)(16 * r + x) * ld) = o;
+    }
 }
 
 // ---- half-width strip with a four-stage ring (tail of an update launch) ---------------------------
@@ -996,7 +1119,10 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   if constexpr (MODE == 0 && S == 1) {
     if (ring) { gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
     if (!g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
-      update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
+      // tile rows of the matrix proper that lie wholly inside n generate their covariance tile (the host decides per
+      // launch and keeps cov_kernel's tile list in step: GroupRun::begin)
+      if (g.fuse_gen && i < g.nt && (i + 1) * kTile <= g.n) update_tile_il_gen(smem, P, ldP, Q, ldQ, Kdim, C, rld, g, b, i);
+      else update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
       return;
     }
   }
@@ -1415,7 +1541,8 @@ __global__ void blocked_grad_reduce_kernel(GradReduceArgs g) {
 size_t blocked_ws_bytes(int npad, int nb, int ne) {
   const int nt = npad / kTile;
   size_t dbl = (size_t)nb * (npad + kTile * (1 + ne)) * npad + (size_t)nb * nt * kTile * kTile +
-               (size_t)nb * (nt + 2) + 64 + (size_t)npad * kMaxD + 16;
+               (size_t)nb * (nt + 2) + 64 + (size_t)npad * kMaxD + 16 +
+               (size_t)nb * kMaxK * npad + ((size_t)(npad / 64) * (npad / 64) + 2 + 1) / 2 + 16;   // upad, tlist
   return dbl * sizeof(double);
 }
 
@@ -1430,6 +1557,8 @@ BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
   w.z = w.invd + (size_t)nb * nt * kTile * kTile;  // logdet partials (nb x nt), then s11 and beta (nb each)
   w.fin = w.z + (size_t)nb * nt;
   w.xpad = w.fin + (((size_t)2 * nb + 15) & ~(size_t)15);   // 128-byte aligned: whole s_load_dwordx16 lines
+  w.upad = w.xpad + (size_t)npad * kMaxD;
+  w.tlist = reinterpret_cast<int*>(w.upad + (size_t)nb * kMaxK * npad);
   return w;
 }
 
@@ -1454,13 +1583,46 @@ struct GroupRun {
   GemmArgs g{};
   DiagArgs dg{};
   int force_s = 0;
+  std::vector<char> fused;   // per block column: whole tiles of its update launch generate their covariance tile
+
+  // Which block columns' update launches generate their own covariance tiles (update_tile_il_gen), and with that the
+  // list of 64 x 64 tiles cov_kernel still has to write: everything of block column 0 and of the columns that are not
+  // fused, and of the fused ones the diagonal tile and the tile rows that reach past n (identity padding).
+  // A column is fused when every one of its tiles below the diagonal runs through update_tile_il: Gaussian family, whole
+  // tiles (no strip option, no tail of ring strips in that launch: their epilogue has another lane layout), 32-bit
+  // buffer offsets, and the epilogue's LDS image within the k-loop's 64 KiB.
+  int plan_fusion() {
+    fused.assign(nt, 0);
+    const int nb8 = round_up(nb, 8), nfull = n / kTile;
+    const bool ok = dv.fam.id == 0 && h->opt_strips == 0 && !h->opt_wide_offsets && !h->opt_no_fused_cov &&
+                    sizeof(double) * gen_lds_doubles(d, dv.K) <= gemm_lds_bytes<1>() &&
+                    (size_t)npad * (size_t)w.ld * 8 < 0xFFFF0000ull;
+    for (int j = 1; j < nt && ok; ++j) {
+      const int tiles = (nt - 1 - j) + w.ne;
+      const bool whole = !h->opt_tail_strips || update_tail(nb8, tiles) == 0;
+      fused[j] = whole && ((size_t)j * kTile + 32) * (size_t)w.ld * 8 < 0xFFFF0000ull;   // fits_buffer_offsets(j * 128, ld)
+    }
+    h->tlist_host.clear();
+    const int nt64 = npad / 64;
+    for (int tr = 0; tr < nt64; ++tr)
+      for (int tc = 0; tc <= tr; ++tc) {
+        const int i = tr / 2, j = tc / 2;
+        if (j >= 1 && fused[j] && i > j && i < nfull) continue;   // generated by the update workgroup that consumes it
+        h->tlist_host.push_back(tr);
+        h->tlist_host.push_back(tc);
+      }
+    return (int)h->tlist_host.size() / 2;
+  }
 
   void begin() {
     const BlockedJob* pr = job && job->kind == kJobPredict ? job : nullptr;
     nt = npad / kTile;
     {
       ScopedTimer t(h, CCGP_T_COV, s);
-      launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld, w.xpad);
+      const int ntl = plan_fusion();
+      (void)hipMemcpyAsync(w.tlist, h->tlist_host.data(), sizeof(int) * 2 * (size_t)ntl, hipMemcpyHostToDevice, s);
+      launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld, w.xpad, w.upad,
+                       w.tlist, ntl);
       RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
       hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad / 16, nb), dim3(256), 0, s, ra);
       if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site
@@ -1476,6 +1638,8 @@ struct GroupRun {
     dg.nb = nb; dg.n = n; dg.ld = w.ld;
     dg.ptol = g.ptol = pivot_tolerance(mean_mode, n);
     force_s = h->opt_strips;   // ccgp_set_option(CCGP_OPT_UPDATE_STRIPS): 0 = whole tiles (+ tail strips)
+    g.xpad = w.xpad; g.upad = w.upad; g.params = dv.params; g.ldp = dv.ldp; g.K = dv.K; g.d = d; g.draw0 = b0;
+    g.mean_mode = mean_mode; g.sigma2 = sigma2; g.tau2 = tau2;
   }
 
   // T_ij = A_ij - sum_{k<j} L_ik L_jk' for every tile row of block column j (nothing to do at j = 0)
@@ -1484,6 +1648,7 @@ struct GroupRun {
     ScopedTimer t(h, CCGP_T_UPDATE, s);
     g.j = j;
     g.mode = 0;
+    g.fuse_gen = fused[j];
     launch_gemm(s, g, 0, force_s > 0 ? force_s : 1);
   }
 

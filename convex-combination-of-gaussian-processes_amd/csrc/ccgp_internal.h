@@ -69,6 +69,8 @@ struct ccgp_handle {
   int opt_strips = 0;                   // CCGP_OPT_UPDATE_STRIPS
   int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
   int opt_small_grid16 = 0;             // CCGP_OPT_SMALL_GRID16
+  int opt_no_fused_cov = 0;             // CCGP_OPT_NO_FUSED_COV
+  std::vector<int> tlist_host;          // cov_kernel's tile list of the sweep in flight (host image of BlockedWs::tlist)
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
   int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
@@ -110,9 +112,13 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
 // Batched lower-triangle tile writer for the blocked path: for draw b0+z, writes
 // s*R_mixed + t into the lower tiles of an npad x npad column-major matrix (identity on
 // the padding), z in [0, nb).  scale/shift: mode 0 -> (1, 0); mode 1 -> (sigma2*sum w^2, tau2).
+// upad (nb x K x npad): u[z][c][i] = sum_k theta_ck x_ik^2 of draw b0 + z, written here once per draw and read by every
+// covariance tile of that draw -- by cov_kernel and by the update workgroups that generate their own tile (blocked.hip).
+// tlist / ntl: the 64 x 64 lower tiles (row tile, column tile) to write, the same list for every matrix; nullptr: all of them.
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2, int ld, double* xpad = nullptr);
+                      double tau2, int ld, double* xpad = nullptr, double* upad = nullptr,
+                      const int* tlist = nullptr, int ntl = 0);
 void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const double* X, int n, int d,
                               DrawView dv, int b0, int nb, double* Abase, size_t batch_stride, int ldo);
 
@@ -160,6 +166,8 @@ struct BlockedWs {
   double* z;        // nb x nt log-det partials
   double* fin;      // nb x 2: s11 = 1'R^-1 1 and beta per matrix (prediction pass)
   double* xpad;     // npad x kMaxD: the design zero-padded to npad rows (scalar-load source of cov_kernel's columns)
+  double* upad;     // nb x kMaxK x npad: u[z][c][i] = sum_k theta_ck x_ik^2 (round 4: shared by cov_kernel and the update)
+  int* tlist;       // (npad / 64)^2 + 2 ints: the 64 x 64 tiles cov_kernel has to write (pairs row tile, column tile)
   size_t a_stride;  // elements between consecutive matrices
   int ld;           // npad + 128 * (1 + ne)
   int ne;           // extra full tile rows (ceil(m / 128) for prediction, else 0)
@@ -275,6 +283,15 @@ __device__ __forceinline__ double exp_cov(double dist, const double* tab) {
   asm("v_fma_f64 %0, %1, %2, %1" : "=v"(v) : "v"(tj), "v"(q));         // T + T (e^r - 1)
   return __builtin_amdgcn_ldexp(v, n >> 8);
 #endif
+}
+
+// One component's term of one mixed-covariance entry: acc + w_c^2 exp(-((u_row + u_col) - 2 sdot)) (HX:352-356, HX:412), in
+// the ONE operation order both producers of a blocked-path entry use -- cov_kernel and the update workgroups that generate
+// their own tile (blocked.hip) -- so that which of them produced a tile cannot be seen in the bits.
+__device__ __forceinline__ double cov_mix_term(double acc, double wc, double u_row, double u_col, double sdot,
+                                               const double* tab) {
+  const double dist = fma(-2.0, sdot, u_row + u_col);
+  return fma(wc, exp_cov(dist, tab), acc);
 }
 
 // exp(-dist) WITHOUT a table: the device library's argument reduction and degree-11 polynomial as explicit

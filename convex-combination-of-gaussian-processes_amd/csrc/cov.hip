@@ -37,6 +37,8 @@ struct CovArgs {
   int npad;
   int raw_mix;      // 1: sum w_c^2 r_c without the division by sum w_c^2 (corr.vec.combined as written, D1F:470-480)
   const double* colpad;   // SCOL instantiation: the design zero-padded to npad rows (npad x d, leading dimension npad)
+  const double* upad;     // SCOL instantiation: u[z][c][i] (nb x K x npad), written by cov_u_kernel
+  const int* tlist;       // lower_tiles: (row tile, column tile) pairs to write; nullptr = every lower tile
 };
 
 // LDS: etab[256] | xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
@@ -55,7 +57,10 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   double* w2 = th + K * d;
 
   int tr = blockIdx.x, tc = blockIdx.y;
-  if (a.lower_tiles) {
+  if (a.lower_tiles && a.tlist) {
+    tr = a.tlist[2 * blockIdx.x];
+    tc = a.tlist[2 * blockIdx.x + 1];
+  } else if (a.lower_tiles) {
     // triangular launch: blockIdx.x enumerates (tr >= tc) pairs of 64-wide tiles
     int t = blockIdx.x;
     int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -75,27 +80,43 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
     double w = a.params[b + (size_t)tid * a.ldp];
     w2[tid] = w * w;
   }
-  for (int e = tid; e < d * kCovRows; e += 256) {
-    int k = e / kCovRows, r = e % kCovRows;
-    int gi = i0 + r;
-    xa[e] = gi < a.m ? a.A[gi + (size_t)k * a.m] : 0.0;
-    int gj = j0 + r;
-    xb[e] = gj < a.n ? a.Bm[gj + (size_t)k * a.n] : 0.0;
-  }
-  __syncthreads();
-  for (int e = tid; e < K * kCovRows; e += 256) {
-    int c = e / kCovRows, r = e % kCovRows;
-    double sa = 0.0, sb = 0.0;
-    for (int k = 0; k < d; ++k) {
-      double t = th[c * d + k];
-      double va = xa[k * kCovRows + r], vb = xb[k * kCovCols + r];
-      sa += va * va * t;  // (X^2 %*% Theta) row sums
-      sb += vb * vb * t;
+  if constexpr (SCOL) {
+    // the row sums u = X^2 Theta come from cov_u_kernel (once per draw; the update workgroups that generate their own tile
+    // read the same values, so both give the same bits), the column coordinates from scalar loads: no xb at all
+    for (int e = tid; e < d * kCovRows; e += 256) {
+      const int k = e / kCovRows, r = e % kCovRows;
+      xa[e] = a.colpad[i0 + r + (size_t)k * a.npad];
     }
-    ua[e] = sa;
-    ub[e] = sb;
+    const double* ub_ = a.upad + (size_t)blockIdx.z * K * a.npad;
+    for (int e = tid; e < K * kCovRows; e += 256) {
+      const int c = e / kCovRows, r = e % kCovRows;
+      ua[e] = ub_[(size_t)c * a.npad + i0 + r];
+      ub[e] = ub_[(size_t)c * a.npad + j0 + r];
+    }
+    __syncthreads();
+  } else {
+    for (int e = tid; e < d * kCovRows; e += 256) {
+      int k = e / kCovRows, r = e % kCovRows;
+      int gi = i0 + r;
+      xa[e] = gi < a.m ? a.A[gi + (size_t)k * a.m] : 0.0;
+      int gj = j0 + r;
+      xb[e] = gj < a.n ? a.Bm[gj + (size_t)k * a.n] : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < K * kCovRows; e += 256) {
+      int c = e / kCovRows, r = e % kCovRows;
+      double sa = 0.0, sb = 0.0;
+      for (int k = 0; k < d; ++k) {
+        double t = th[c * d + k];
+        double va = xa[k * kCovRows + r], vb = xb[k * kCovCols + r];
+        sa += va * va * t;  // (X^2 %*% Theta) row sums
+        sb += vb * vb * t;
+      }
+      ua[e] = sa;
+      ub[e] = sb;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   double sw = 0.0;
   for (int c = 0; c < K; ++c) sw += w2[c];
@@ -149,8 +170,12 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
     const double ur = ua[c * kCovRows + lane], wc = w2[c];
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
-      const double dist = (ur + ub[c * kCovCols + jl0 + jj]) + (-2.0 * sdot[jj]);
-      accs[jj] = fma(wc, (FAM == 0 ? exp_cov(dist, etab) : corr_of_dist(a.fam, dist, etab, c)), accs[jj]);
+      if constexpr (FAM == 0) {
+        accs[jj] = cov_mix_term(accs[jj], wc, ur, ub[c * kCovCols + jl0 + jj], sdot[jj], etab);
+      } else {
+        const double dist = (ur + ub[c * kCovCols + jl0 + jj]) + (-2.0 * sdot[jj]);
+        accs[jj] = fma(wc, corr_of_dist(a.fam, dist, etab, c), accs[jj]);
+      }
     }
   }
   if constexpr (SCOL) {
@@ -236,9 +261,23 @@ __global__ void pad_design_kernel(const double* X, int n, int d, int npad, doubl
 }
 }  // namespace
 
+namespace {
+// u[z][c][i] = sum_k theta_ck x_ik^2 (the row sums of X^2 Theta, HX:352-353) for draw b0 + z: zero on the padding rows
+__global__ void cov_u_kernel(const double* xpad, int npad, int d, const double* params, int ldp, int K, int b0, double* upad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, z = blockIdx.z;
+  if (i >= npad) return;
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double v = xpad[i + (size_t)k * npad];
+    s = fma(v * v, params[b0 + z + (size_t)(K + c * d + k) * ldp], s);
+  }
+  upad[((size_t)z * K + c) * npad + i] = s;
+}
+}  // namespace
+
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2, int ld, double* xpad) {
+                      double tau2, int ld, double* xpad, double* upad, const int* tlist, int ntl) {
   CovArgs a{};
   a.A = X; a.Bm = X; a.m = n; a.n = n; a.d = d;
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
@@ -246,13 +285,17 @@ void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv,
   a.sigma2 = sigma2; a.tau2 = tau2; a.lower_tiles = 1; a.npad = npad;
   cov_prepare();
   int nt64 = npad / 64;
-  dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
+  dim3 grid(tlist ? ntl : nt64 * (nt64 + 1) / 2, 1, nb);
+  a.tlist = tlist;
   // the scalar-column instantiation addresses a matrix through 32-bit buffer offsets
   const bool fits32 = (size_t)npad * (size_t)ld * 8 < 0xFFFF0000ull;
-  if (dv.fam.id == 0 && xpad && fits32) {
+  if (dv.fam.id == 0 && xpad && upad && fits32) {
     hipLaunchKernelGGL(pad_design_kernel, dim3((npad * d + 255) / 256), dim3(256), 0, s, X, n, d, npad, xpad);
+    hipLaunchKernelGGL(cov_u_kernel, dim3((npad + 255) / 256, dv.K, nb), dim3(256), 0, s, xpad, npad, d, dv.params, dv.ldp,
+                       dv.K, b0, upad);
     a.colpad = xpad;
-    hipLaunchKernelGGL((cov_kernel<0, true>), grid, dim3(256), cov_lds(d, dv.K), s, a);
+    a.upad = upad;
+    if (grid.x) hipLaunchKernelGGL((cov_kernel<0, true>), grid, dim3(256), cov_lds(d, dv.K), s, a);
   } else if (dv.fam.id == 0) {
     hipLaunchKernelGGL(cov_kernel<0>, grid, dim3(256), cov_lds(d, dv.K), s, a);
   } else {

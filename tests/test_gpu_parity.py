@@ -487,6 +487,77 @@ def test_update_loops_with_buffer_offsets_and_with_pointers_give_the_same_bits(h
     assert got[0][0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.3)[0], rel=1e-9)
 
 
+@pytest.mark.parametrize("n,d,K,B", [(300, 4, 2, 9), (1100, 5, 3, 8), (1024, 5, 3, 16), (1537, 2, 4, 3)])
+def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits(handle, n, d, K, B):
+    """Since round 4 a whole tile of the trailing update generates its covariance tile in the epilogue of the workgroup
+    that consumes it (blocked.hip: update_tile_il_gen) and cov_kernel writes only the tiles of a host-built list (column
+    0, diagonal tiles, ragged edge rows, columns whose launch has tail strips).  Both evaluate every entry through
+    cov_mix_term on the same u = sum theta x^2 table, so OPT_NO_FUSED_COV (cov_kernel writes everything, the update reads
+    it) must give the same bits: log-likelihood in both mean modes (a failing draw included), prediction (extra tile
+    rows) and gradient (identity rows); n a multiple of 128 and ragged, draw counts with and without a ragged group."""
+    from ccgp_amd import api
+    X, y = synthetic_design(n, d, seed=5 * n)
+    rng = np.random.default_rng(n + B)
+    P = np.empty((B, K + K * d))
+    for b in range(B):
+        w = rng.dirichlet(np.ones(K))
+        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
+        th[-1] = np.maximum(th[-1], 2.0 * n ** (2.0 / d) / d)
+        P[b] = np.concatenate([w, th.ravel()])
+    P[B - 1, K:] = 0.0                               # R = 11': the factorisation fails in block column 0 or 1
+    Xt = rng.random((70, d))
+    def run():
+        out = []
+        for mode, tau2 in ((api.MEAN_PROFILE_BETA, 0.0), (api.MEAN_ZERO_PLUS_TAU2, 4.0)):
+            out += list(handle.loglik_batch(X, y, K, P, 1.3, mode, tau2))
+        out += list(handle.predict_batch(X, y, K, P[:2], Xt, 1.3))
+        out += list(handle.loglik_grad_batch(X, y, K, P[:2], 1.3))
+        return out
+    got = run()
+    handle.set_option(api.OPT_NO_FUSED_COV, 1)
+    try:
+        want = run()
+    finally:
+        handle.set_option(api.OPT_NO_FUSED_COV, 0)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    assert got[2][B - 1] != 0 and not got[2][:B - 1].any() and np.isfinite(got[0][:B - 1]).all()
+    w, Th = orc.unpack_params(P[0], K, d)
+    assert got[0][0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.3)[0], rel=1e-8)
+
+
+def test_fused_generation_leaves_cov_kernel_only_the_listed_tiles(handle):
+    """The point of the fusion: at n = 2048 (16 tile rows) cov_kernel still writes block column 0 and the diagonal tiles,
+    about a quarter of the lower triangle.  Its share of the device time must drop accordingly -- a check that the fused
+    path is the one that runs by default (a plan that silently fused nothing would still pass the bitwise test above)."""
+    from ccgp_amd import api
+    n, d, K, B = 2048, 5, 3, 16
+    X, y = synthetic_design(n, d, seed=11)
+    rng = np.random.default_rng(11)
+    P = np.empty((B, K + K * d))
+    for b in range(B):
+        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
+        th[-1] = np.maximum(th[-1], 20.0)
+        P[b] = np.concatenate([rng.dirichlet(np.ones(K)), th.ravel()])
+    def cov_ms(off):
+        handle.set_option(api.OPT_NO_FUSED_COV, off)
+        handle.loglik_batch(X, y, K, P, 1.0)          # warm-up (workspace, clocks)
+        handle.enable_timing(True)
+        try:
+            for _ in range(3):
+                ll, _, st = handle.loglik_batch(X, y, K, P, 1.0)
+            best = handle.get_timing()["cov"][0]      # accumulated over the three evaluations
+        finally:
+            handle.enable_timing(False)
+            handle.set_option(api.OPT_NO_FUSED_COV, 0)
+        assert not st.any()
+        return best, ll
+    fused, a = cov_ms(0)
+    plain, b = cov_ms(1)
+    np.testing.assert_array_equal(a, b)
+    assert fused < 0.6 * plain, (fused, plain)
+
+
 def test_small_and_blocked_agree_across_the_cutover(handle):
     """n = 128 runs the fused kernel, n = 129 the blocked one: appending one far-away,
     nearly independent point must change the likelihood by exactly its own marginal term."""

@@ -349,8 +349,8 @@ def parse_args():
                     help="pin the update kernel's column-strip count (ccgp_set_option; 0 = per-launch choice)")
     ap.add_argument("--no-tail-strips", action="store_true", help="every update tile whole (ccgp_set_option; measurements)")
     ap.add_argument("--no-fuse-diag", action="store_true", help="separate diag_kernel launches (ccgp_set_option; measurements)")
-    ap.add_argument("--no-fused-cov", action="store_true",
-                    help="cov_kernel writes every tile, the update reads them (rounds 1 - 3; ccgp_set_option; measurements)")
+    ap.add_argument("--fused-cov", action="store_true",
+                    help="whole update tiles generate their covariance tile, cov_kernel writes the rest (ccgp_set_option; measurements)")
     ap.add_argument("--small-grid16", action="store_true",
                     help="64 < n <= 104 on the 16 x 16 thread grid of rounds 1 - 3 instead of one wave per matrix (ccgp_set_option; measurements)")
     ap.add_argument("--ws-limit-gib", type=float, default=0.0,
@@ -512,8 +512,8 @@ def run_loglik_workload(c):
         h.set_option(api.OPT_FUSE_DIAG, 0)
     if args.small_grid16:
         h.set_option(api.OPT_SMALL_GRID16, 1)
-    if args.no_fused_cov:
-        h.set_option(api.OPT_NO_FUSED_COV, 1)
+    if args.fused_cov:
+        h.set_option(api.OPT_FUSED_COV, 1)
     if args.ws_limit_gib > 0:
         h.set_workspace_limit(int(args.ws_limit_gib * 2 ** 30))
     h.reserve(n, d, K, max(B, 1), 0)

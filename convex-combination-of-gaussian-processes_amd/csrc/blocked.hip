@@ -1017,7 +1017,7 @@ __host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, in
   return mode == 0 ? 1 + ((nt - 1 - j) + ne) * S : (nt - j) + ne;
 }
 
-template <int MODE, int S>
+template <int MODE, int S, bool GEN = false>
 __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   const int L = blockIdx.x;
   const int ld = g.ld;
@@ -1119,10 +1119,16 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   if constexpr (MODE == 0 && S == 1) {
     if (ring) { gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
     if (!g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
-      // tile rows of the matrix proper that lie wholly inside n generate their covariance tile (the host decides per
-      // launch and keeps cov_kernel's tile list in step: GroupRun::begin)
-      if (g.fuse_gen && i < g.nt && (i + 1) * kTile <= g.n) update_tile_il_gen(smem, P, ldP, Q, ldQ, Kdim, C, rld, g, b, i);
-      else update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
+      // GEN (chol_update_gen_kernel, CCGP_OPT_FUSED_COV): tile rows of the matrix proper that lie wholly inside n generate
+      // their covariance tile (the host decides per launch and keeps cov_kernel's tile list in step: GroupRun::begin).
+      // A kernel of its own: the generating epilogue needs 256 VGPRs and 200 B of scratch, the plain one neither.
+      if constexpr (GEN) {
+        if (i < g.nt && (i + 1) * kTile <= g.n) {
+          update_tile_il_gen(smem, P, ldP, Q, ldQ, Kdim, C, rld, g, b, i);
+          return;
+        }
+      }
+      update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
       return;
     }
   }
@@ -1130,16 +1136,17 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
 }
 
 // distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
-#define CCGP_DEFINE_GEMM(NAME, MODE, S, WPS)                                            \
+#define CCGP_DEFINE_GEMM(NAME, MODE, S, WPS, GEN)                                       \
   __global__ __launch_bounds__(256, WPS) void NAME(GemmArgs g) {                        \
     extern __shared__ __attribute__((aligned(16))) double smem[];                       \
-    gemm_dispatch<MODE, S>(g, smem);                                                     \
+    gemm_dispatch<MODE, S, GEN>(g, smem);                                                \
   }
-CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2)
-CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
+CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2, false)
+CCGP_DEFINE_GEMM(chol_update_gen_kernel, 0, 1, 2, true)
+CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2, false)
 // trsm exists at S = 1 only: it is in place (reads the whole tile row, writes its own columns), so column
 // strips of one tile would race
-CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
+CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2, false)
 #undef CCGP_DEFINE_GEMM
 
 // Strip count of an update launch: always 1 since round 2.  One workgroup per SIMD-set saturates a CU's four MFMA
@@ -1174,7 +1181,8 @@ static void launch_gemm(hipStream_t s, GemmArgs g, int mode, int S) {
   }
   const dim3 grid(units), block(256);
   if (mode == 0) {
-    if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
+    if (S == 1 && g.fuse_gen) hipLaunchKernelGGL(chol_update_gen_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
+    else if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
     else hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
   } else {
     hipLaunchKernelGGL(chol_trsm_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
@@ -1594,7 +1602,7 @@ struct GroupRun {
   int plan_fusion() {
     fused.assign(nt, 0);
     const int nb8 = round_up(nb, 8), nfull = n / kTile;
-    const bool ok = dv.fam.id == 0 && h->opt_strips == 0 && !h->opt_wide_offsets && !h->opt_no_fused_cov &&
+    const bool ok = dv.fam.id == 0 && h->opt_strips == 0 && !h->opt_wide_offsets && h->opt_fused_cov &&
                     sizeof(double) * gen_lds_doubles(d, dv.K) <= gemm_lds_bytes<1>() &&
                     (size_t)npad * (size_t)w.ld * 8 < 0xFFFF0000ull;
     for (int j = 1; j < nt && ok; ++j) {
@@ -1728,6 +1736,7 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   static unsigned long long attr_mask = 0;
   once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)chol_update_kernel, "chol_update_kernel");
+    raise_lds_limit((const void*)chol_update_gen_kernel, "chol_update_gen_kernel");
     raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
     raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
     raise_lds_limit((const void*)rinv_tile_kernel<false>, "rinv_tile_kernel<false>");
@@ -1759,6 +1768,7 @@ void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int
   static unsigned long long attr_mask = 0;
   once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)chol_update_kernel, "chol_update_kernel");
+    raise_lds_limit((const void*)chol_update_gen_kernel, "chol_update_gen_kernel");
     raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
     raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
   });

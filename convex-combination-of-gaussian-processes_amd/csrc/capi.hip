@@ -553,8 +553,8 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
     h->opt_small_grid16 = value;
     return CCGP_OK;
   }
-  if (option == CCGP_OPT_NO_FUSED_COV && (value == 0 || value == 1)) {
-    h->opt_no_fused_cov = value;
+  if (option == CCGP_OPT_FUSED_COV && (value == 0 || value == 1)) {
+    h->opt_fused_cov = value;
     return CCGP_OK;
   }
   return fail(h, CCGP_EINVAL, "ccgp_set_option: unknown option or value");

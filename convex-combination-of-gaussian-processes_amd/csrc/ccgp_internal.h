@@ -69,7 +69,7 @@ struct ccgp_handle {
   int opt_strips = 0;                   // CCGP_OPT_UPDATE_STRIPS
   int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
   int opt_small_grid16 = 0;             // CCGP_OPT_SMALL_GRID16
-  int opt_no_fused_cov = 0;             // CCGP_OPT_NO_FUSED_COV
+  int opt_fused_cov = 0;                // CCGP_OPT_FUSED_COV
   std::vector<int> tlist_host;          // cov_kernel's tile list of the sweep in flight (host image of BlockedWs::tlist)
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS

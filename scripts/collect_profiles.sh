@@ -8,12 +8,15 @@ mkdir -p $P
 for f in bench_default bench_slice64 bench_cfg2 bench_cfg3 bench_cfg3_grid16 bench_cfg5; do [ -f $G/$f.json ] && tail -1 $G/$f.json > $P/$f.json; done
 cp $G/stats/t_kernel_stats.csv $P/kernel_stats_stats.csv
 cp $G/stats64/t_kernel_stats.csv $P/kernel_stats_stats64.csv
+cp $G/statsfc/t_kernel_stats.csv $P/kernel_stats_stats_fused_cov.csv
+cp $G/fused_cov_ab.txt $P/fused_cov_ab.txt
 cp $G/stats_cfg2/t_kernel_stats.csv $P/kernel_stats_stats_cfg2.csv
 cp $G/stats_cfg3/t_kernel_stats.csv $P/kernel_stats_stats_cfg3.csv
 cp $G/valu_f64_rates.txt $P/valu_f64_rates.txt
 cp $G/mfma_valu_overlap.txt $P/mfma_valu_overlap.txt
 python3 scripts/pmc_summary.py $TAG > /dev/null
 python3 scripts/pmc_summary.py $TAG 64 64 > /dev/null
+python3 scripts/pmc_summary.py $TAG fc 512 > /dev/null
 python3 scripts/pmc_sq_summary.py $TAG > /dev/null
 python3 scripts/pmc_cfg2_summary.py $TAG cfg2 > /dev/null
 python3 scripts/pmc_cfg2_summary.py $TAG cfg3 > /dev/null

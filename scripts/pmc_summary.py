@@ -5,7 +5,7 @@ FETCH_SIZE counts 128-B requests at 64 B for 16 B/lane coalesced reads -> double
 both counters are in units of 64 B... the csv already reports bytes/ kilobytes as labelled by rocprofv3)."""
 import csv, json, re, sys, collections
 tag = sys.argv[1]
-suffix = sys.argv[2] if len(sys.argv) > 2 else ''          # '' = the 512-matrix run, '64' = the 64-matrix slice
+suffix = sys.argv[2] if len(sys.argv) > 2 else ''          # '' = the 512-matrix run, '64' = the 64-matrix slice, 'fc' = --fused-cov
 nmat = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 base = 'gpurun_out/%s' % tag
 def per_kernel(path, counter):
@@ -19,7 +19,7 @@ def per_kernel(path, counter):
     return agg, {k: len(v) for k, v in launches.items()}
 f, nf = per_kernel(base + '/pmc_fetch%s/t_counter_collection.csv' % suffix, 'FETCH_SIZE')
 w, nw = per_kernel(base + '/pmc_write%s/t_counter_collection.csv' % suffix, 'WRITE_SIZE')
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary%s; MI355X, cfg4 n=4096, %d matrices per launch" % (" --evals-total %d" % nmat if nmat != 512 else "", nmat),
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary%s; MI355X, cfg4 n=4096, %d matrices per launch" % ((" --evals-total %d" % nmat if nmat != 512 else "") + (" --fused-cov" if suffix == "fc" else ""), nmat),
        "matrices_per_launch": nmat,
        "correction": "counters reported in KiB; gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16 B/lane coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is",
        "kernels": {}}

@@ -24,6 +24,19 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o t --output-f
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o t --output-format csv -- $B > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o t --output-format csv -- $B > $OUT/pmc_write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace -d $OUT/pmc_sq -o t --output-format csv -- $B > $OUT/pmc_sq.log 2>&1
+# cov_kernel writing every tile (default) against covariance tiles generated in the update (--fused-cov = CCGP_OPT_FUSED_COV):
+# alternating bench lines, kernel stats and the two traffic passes of the fused data flow beside the default ones above
+: > $OUT/fused_cov_ab.txt
+for o in "" "--fused-cov" "" "--fused-cov"; do
+  python3 $R/bench.py --steps 5 --no-cpu-baseline --no-secondary $o 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('%-16s %7.2f ms per step  %s  digest %s' % ('$o' or 'default', d['ms_per_step'], {k: round(v, 2) for k, v in d['kernel_ms_per_step'].items()}, d['config']['matches_cpu_potrf_digest']))" >> $OUT/fused_cov_ab.txt
+done
+cat $OUT/fused_cov_ab.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/statsfc -o t --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --fused-cov > $OUT/statsfc.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetchfc -o t --output-format csv -- $B --fused-cov > $OUT/pmc_fetchfc.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_writefc -o t --output-format csv -- $B --fused-cov > $OUT/pmc_writefc.log 2>&1
 # cov_kernel: the three SQ passes that cfg2 / cfg3 have
 i=0
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"; do

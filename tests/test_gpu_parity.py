@@ -489,11 +489,11 @@ def test_update_loops_with_buffer_offsets_and_with_pointers_give_the_same_bits(h
 
 @pytest.mark.parametrize("n,d,K,B", [(300, 4, 2, 9), (1100, 5, 3, 8), (1024, 5, 3, 16), (1537, 2, 4, 3)])
 def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits(handle, n, d, K, B):
-    """Since round 4 a whole tile of the trailing update generates its covariance tile in the epilogue of the workgroup
-    that consumes it (blocked.hip: update_tile_il_gen) and cov_kernel writes only the tiles of a host-built list (column
-    0, diagonal tiles, ragged edge rows, columns whose launch has tail strips).  Both evaluate every entry through
-    cov_mix_term on the same u = sum theta x^2 table, so OPT_NO_FUSED_COV (cov_kernel writes everything, the update reads
-    it) must give the same bits: log-likelihood in both mean modes (a failing draw included), prediction (extra tile
+    """OPT_FUSED_COV (round 4): a whole tile of the trailing update generates its covariance tile in the epilogue of the
+    workgroup that consumes it (blocked.hip: update_tile_il_gen, chol_update_gen_kernel) and cov_kernel writes only the tiles
+    of a host-built list (column 0, diagonal tiles, ragged edge rows, columns whose launch has tail strips).  Both evaluate
+    every entry through cov_mix_term on the same u = sum theta x^2 table, so the default data flow (cov_kernel writes
+    everything, the update reads it) must give the same bits: log-likelihood in both mean modes (a failing draw included), prediction (extra tile
     rows) and gradient (identity rows); n a multiple of 128 and ragged, draw counts with and without a ragged group."""
     from ccgp_amd import api
     X, y = synthetic_design(n, d, seed=5 * n)
@@ -513,12 +513,12 @@ def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits
         out += list(handle.predict_batch(X, y, K, P[:2], Xt, 1.3))
         out += list(handle.loglik_grad_batch(X, y, K, P[:2], 1.3))
         return out
-    got = run()
-    handle.set_option(api.OPT_NO_FUSED_COV, 1)
+    want = run()
+    handle.set_option(api.OPT_FUSED_COV, 1)
     try:
-        want = run()
+        got = run()
     finally:
-        handle.set_option(api.OPT_NO_FUSED_COV, 0)
+        handle.set_option(api.OPT_FUSED_COV, 0)
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, b)
     assert got[2][B - 1] != 0 and not got[2][:B - 1].any() and np.isfinite(got[0][:B - 1]).all()
@@ -528,8 +528,8 @@ def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits
 
 def test_fused_generation_leaves_cov_kernel_only_the_listed_tiles(handle):
     """The point of the fusion: at n = 2048 (16 tile rows) cov_kernel still writes block column 0 and the diagonal tiles,
-    about a quarter of the lower triangle.  Its share of the device time must drop accordingly -- a check that the fused
-    path is the one that runs by default (a plan that silently fused nothing would still pass the bitwise test above)."""
+    about a quarter of the lower triangle.  Its share of the device time must drop accordingly -- a check that the option
+    really switches the generating kernel in (a plan that silently fused nothing would still pass the bitwise test above)."""
     from ccgp_amd import api
     n, d, K, B = 2048, 5, 3, 16
     X, y = synthetic_design(n, d, seed=11)
@@ -539,8 +539,8 @@ def test_fused_generation_leaves_cov_kernel_only_the_listed_tiles(handle):
         th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
         th[-1] = np.maximum(th[-1], 20.0)
         P[b] = np.concatenate([rng.dirichlet(np.ones(K)), th.ravel()])
-    def cov_ms(off):
-        handle.set_option(api.OPT_NO_FUSED_COV, off)
+    def cov_ms(on):
+        handle.set_option(api.OPT_FUSED_COV, on)
         handle.loglik_batch(X, y, K, P, 1.0)          # warm-up (workspace, clocks)
         handle.enable_timing(True)
         try:
@@ -549,11 +549,11 @@ def test_fused_generation_leaves_cov_kernel_only_the_listed_tiles(handle):
             best = handle.get_timing()["cov"][0]      # accumulated over the three evaluations
         finally:
             handle.enable_timing(False)
-            handle.set_option(api.OPT_NO_FUSED_COV, 0)
+            handle.set_option(api.OPT_FUSED_COV, 0)
         assert not st.any()
         return best, ll
-    fused, a = cov_ms(0)
-    plain, b = cov_ms(1)
+    fused, a = cov_ms(1)
+    plain, b = cov_ms(0)
     np.testing.assert_array_equal(a, b)
     assert fused < 0.6 * plain, (fused, plain)
 

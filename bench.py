@@ -501,6 +501,7 @@ def run_loglik_workload(c):
                                        "GV n=%d" % gvX.shape[0]: cpu_predict_post_latency(gvX, gvy, gvXt[0], 10.0)}
             if args.n == 4096:
                 cpu_sec["cfg4_predict"] = cpu_predict_n4096(X, y, K, P[:CFG4_PREDICT_DRAWS], sigma2)
+                cpu_sec["cfg4_gradient"], cpu_sec["cfg4_gradient_fd"] = cpu_gradient_n4096(X, y, K, P[0], sigma2)
 
     h = api.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -836,6 +837,27 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
             "factorset_bytes": fs.nbytes, "identical": bool(np.array_equal(m_a, m_b) and np.array_equal(v_a, v_b)),
             "cpu": cpu_sec.get("cfg4_predict")})
         fs.free()
+        # analytic gradient at the headline size (the reference differences logpost numerically: LearnBayes::laplace, HX:493)
+        Pg = np.asfortranarray(P[:Sf])
+        h.loglik_grad_batch(X, y, K, Pg, sigma2)
+        t1 = time.perf_counter()
+        gll, _, gg, gst = h.loglik_grad_batch(X, y, K, Pg, sigma2)
+        t_grad = time.perf_counter() - t1
+        h.loglik_batch(X, y, K, Pg, sigma2)
+        t1 = time.perf_counter()
+        pll, _, _ = h.loglik_batch(X, y, K, Pg, sigma2)
+        t_ll = time.perf_counter() - t1
+        item = {"workload": "cfg4 gradient: n=4096, %d draws, log-likelihood + d/d(w, theta) (%d parameters) through "
+                            "ccgp_loglik_grad_batch (host pointers)" % (Sf, Pg.shape[1]),
+                "value": Sf / t_grad, "unit": "gradients/s", "ms_per_call": 1e3 * t_grad,
+                "ms_same_call_without_gradient": 1e3 * t_ll, "failed": int(np.count_nonzero(gst)),
+                "loglik_identical_to_plain_call": bool(np.array_equal(gll, pll)),
+                "cpu": cpu_sec.get("cfg4_gradient")}
+        fd = cpu_sec.get("cfg4_gradient_fd")
+        if fd is not None:
+            item["rel_dev_from_cpu_central_differences_max"] = float(
+                np.max(np.abs(gg[0] - fd) / (np.abs(fd) + 1e-3 * np.abs(fd).max())))
+        items.append(item)
     return items
 
 
@@ -854,6 +876,25 @@ def cpu_predict_n4096(X, y, K, P, sigma2):
     return {"all_cores": P.shape[0] * Xt.shape[0] / el, "cores": cores, "unit": "(draw, test point) predictions/s",
             "ms": 1e3 * el, "sample": "%d draws x %d sites, re-factorising (covariance + dpotrf + %d dtrsv per draw), one draw "
                                       "per core on %d cores in %.2f s" % (P.shape[0], Xt.shape[0], Xt.shape[0] + 2, cores, el)}
+
+
+def cpu_gradient_n4096(X, y, K, row, sigma2):
+    """ONE gradient at n = 4096 by central differences of the compiled evaluator: 2 P evaluations, one per core."""
+    from oracle.cpu_baseline import loader as cpu
+    cores = cpu.max_threads()
+    Pn = row.size
+    hstep = 1e-5
+    big = np.repeat(row[None], 2 * Pn, axis=0)
+    for j in range(Pn):
+        big[2 * j, j] += hstep * abs(row[j])
+        big[2 * j + 1, j] -= hstep * abs(row[j])
+    t0 = time.perf_counter()
+    ll = np.asarray(cpu.loglik_batch(X, y, K, big, sigma2, 0, 0.0, threads=cores)[0]).reshape(Pn, 2)
+    el = time.perf_counter() - t0
+    g = (ll[:, 0] - ll[:, 1]) / (2 * hstep * np.abs(row))
+    return {"all_cores": 1.0 / el, "cores": cores, "unit": "gradients/s",
+            "sample": "1 gradient = %d likelihood evaluations (central differences in %d parameters), one per core on %d "
+                      "cores in %.2f s" % (2 * Pn, Pn, cores, el)}, g
 
 
 def run_predict_workload(c):

@@ -1344,24 +1344,37 @@ struct AlphaArgs {
   double* alpha;        // nb x npad:  R^-1 (y - beta 1) = Z (z_y - beta z_1)
 };
 
+// A workgroup owns 64 rows (lane = row: a column of Z is read as 512 contiguous bytes per wave), its four waves take the
+// columns c = a0 + w, a0 + w + 4, ...; fixed summation order.  (Rounds 2 - 3: one thread per row walking its up to n columns
+// alone -- 3.2 ms for 16 draws at n = 4096, half as long as forming R^-1.)
 __global__ __launch_bounds__(256) void alpha_kernel(AlphaArgs g) {
-  const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= g.npad) return;
+  __shared__ double part[4][64];
+  const int b = blockIdx.y, a0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = a0 + lane;
   const double* Ab = g.A + (size_t)b * g.a_stride;
   const double* zrow = Ab + g.npad;
   const double* Zrow = Ab + g.npad + kTile + a;
   const double beta = g.beta[b];
   double s = 0.0;
-  if (a < g.n)
-    for (int c = a; c < g.n; ++c)
-      s = fma(Zrow[(size_t)c * g.ld], zrow[(size_t)c * g.ld] - beta * zrow[1 + (size_t)c * g.ld], s);
-  g.alpha[(size_t)b * g.npad + a] = s;
+  if (a < g.n) {
+#pragma unroll 4
+    for (int c = a0 + wave; c < g.n; c += 4) {
+      const double z = Zrow[(size_t)c * g.ld];
+      const double v = zrow[(size_t)c * g.ld] - beta * zrow[1 + (size_t)c * g.ld];
+      if (c >= a) s = fma(z, v, s);
+    }
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (tid < 64) g.alpha[(size_t)b * g.npad + a0 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
 struct RinvArgs {
   const double* A;
   size_t a_stride;
   int npad, ld, nt, n, nb;
+  int wide;              // CCGP_OPT_WIDE_OFFSETS: the 64-bit-pointer loop everywhere
   // inverse
   double* Rinv;          // nb matrices of n x n
   // gradient
@@ -1374,16 +1387,82 @@ struct RinvArgs {
   double* gpart;         // nb x ntiles x P
 };
 
-// One 128 x 128 tile (ta >= tb) of R^-1 = Z Z' (k from block ta on, where both row blocks are
-// non-zero), kept in registers and either written out (GRAD = false) or contracted on the spot
-// with the kernel derivatives (GRAD = true):
-//   M = (alpha alpha' - R^-1 / c) / 2,  c = sigma2 sum w^2,  alpha = R^-1 (y - beta 1) / c
-//   d loglik / d w_q      =  2 sigma2 w_q     sum_ab M_ab R_q,ab
-//   d loglik / d theta_qk = -  sigma2 w_q^2   sum_ab M_ab (x_ak - x_bk)^2 R_q,ab
-// R_q is regenerated from X (never stored).  One workgroup per CU (512 VGPRs): the tile of M R_q
-// lives in registers next to the accumulators.
+// One 128 x 128 tile (ta >= tb) of R^-1 = Z Z' (k from block ta on, where both row blocks are non-zero), kept in
+// registers and either written out symmetrically (GRAD = false: solve(R), HX:454) or turned into the tile of
+//   M = (alpha alpha' - R^-1 / c) / 2,   c = sigma2 sum w^2,   alpha = R^-1 (y - beta 1) / c
+// and stored over the (no longer needed) tile (ta, tb) of L, zero outside the n x n matrix (GRAD = true); the
+// contraction with the kernel derivatives is grad_contract_kernel's.
+// Round 4: the product runs on the update's round-3 loop (tile_accumulate_il: buffer-offset stage requests, b128 fragment
+// reads; the round-2 loop remains for panels of 4 GiB and more, same bits) with TWO workgroups per CU.  Rounds 2 - 3
+// contracted in this kernel's epilogue: the tile of M .* R_q in a second set of 128 registers beside the accumulators
+// (512 VGPRs: one workgroup per CU, the round-2 loop alone on its CU -- 30 TFLOP/s), and every attempt to contract without
+// that second set under 256 registers ended in kilobytes of scratch (14.6 -> 25.6 ms per 16 draws at n = 4096).  A round
+// trip of M through HBM costs 2 x 67 MB per draw -- 0.03 ms at 5 TB/s -- and leaves each kernel with one job.
+template <bool IL>
+struct RinvMap {
+  int row0, col0, l15, l4;
+  __device__ RinvMap() {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    row0 = (wave >> 1) * 64; col0 = (wave & 1) * 64; l15 = lane & 15; l4 = lane >> 4;
+  }
+  __device__ __forceinline__ int row(int y) const { return IL ? row0 + 4 * l15 + y : row0 + 16 * y + l15; }
+  __device__ __forceinline__ int col(int x, int r) const { return IL ? col0 + 16 * r + 4 * l4 + x : col0 + 16 * x + l4 + 4 * r; }
+};
+
+template <bool GRAD, bool IL>
+__device__ __forceinline__ void rinv_tile_finish(const RinvArgs& g, d4 (&acc)[4][4], int b, int ta, int tb) {
+  // acc[x][y][r] = Rinv[row = ta*128 + map.row(y)][col = tb*128 + map.col(x, r)]
+  const RinvMap<IL> map;
+  const int n = g.n;
+  if constexpr (!GRAD) {
+    double* out = g.Rinv + (size_t)b * n * n;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ga = ta * kTile + map.row(y), gb = tb * kTile + map.col(x, r);
+          if (ga < n && gb < n) {
+            out[ga + (size_t)gb * n] = acc[x][y][r];
+            out[gb + (size_t)ga * n] = acc[x][y][r];
+          }
+        }
+  } else {
+    const int gdraw = g.draw0 + b;
+    double sw = 0.0;
+    for (int q = 0; q < g.K; ++q) { const double w = g.params[gdraw + (size_t)q * g.ldp]; sw += w * w; }
+    const double cs = g.sigma2 * sw;
+    const double* al = g.alpha + (size_t)b * g.npad;
+    double* Mt = const_cast<double*>(g.A) + (size_t)b * g.a_stride + (size_t)ta * kTile + (size_t)tb * kTile * g.ld;
+    double ala[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) ala[y] = al[ta * kTile + map.row(y)];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lc = map.col(x, r), gb = tb * kTile + lc;
+        const double alb = al[gb];
+        d4 o;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          const int ga = ta * kTile + map.row(y);
+          const double m = 0.5 * (ala[y] * alb / (cs * cs) - acc[x][y][r] / cs);
+          o[y] = (ga < n && gb < n) ? m : 0.0;
+        }
+        if constexpr (IL) {
+          *(d4*)(Mt + map.row(0) + (size_t)lc * g.ld) = o;     // a lane's four rows are contiguous
+        } else {
+#pragma unroll
+          for (int y = 0; y < 4; ++y) Mt[map.row(y) + (size_t)lc * g.ld] = o[y];
+        }
+      }
+  }
+}
+
 template <bool GRAD>
-__global__ __launch_bounds__(256, 1) void rinv_tile_kernel(RinvArgs g) {
+__global__ __launch_bounds__(256, 2) void rinv_tile_kernel(RinvArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int ntiles = g.nt * (g.nt + 1) / 2;
   const int L = blockIdx.x;
@@ -1400,124 +1479,146 @@ __global__ __launch_bounds__(256, 1) void rinv_tile_kernel(RinvArgs g) {
   const double* Zb = g.A + (size_t)b * g.a_stride + g.npad + kTile;
   const double* P = Zb + (size_t)ta * kTile + (size_t)ta * kTile * g.ld;
   const double* Q = Zb + (size_t)tb * kTile + (size_t)ta * kTile * g.ld;
+  const int Kdim = g.npad - ta * kTile;
   d4 acc[4][4];
-  gemm_accumulate<1, false>(smem, P, g.ld, Q, g.ld, g.npad - ta * kTile, acc);
-  // acc[x][y][r] = Rinv[row = ta*128 + row0 + 16y + l15][col = tb*128 + col0 + 16x + l4 + 4r]
+  if (!g.wide && fits_buffer_offsets(Kdim, g.ld)) {   // uniform
+    tile_accumulate_il(smem, P, g.ld, Q, g.ld, Kdim, acc);
+    rinv_tile_finish<GRAD, true>(g, acc, b, ta, tb);
+  } else {                                            // 64-bit-pointer loop, same bits
+    gemm_accumulate<1, false>(smem, P, g.ld, Q, g.ld, Kdim, acc);
+    rinv_tile_finish<GRAD, false>(g, acc, b, ta, tb);
+  }
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = TileGeom<1, false>::row0(wave), col0 = TileGeom<1, false>::col0(wave);
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int n = g.n;
-  if constexpr (!GRAD) {
-    double* out = g.Rinv + (size_t)b * n * n;
+// ---- gradient: M contracted with the kernel derivatives ------------------------------------------------
+//   d loglik / d w_q      =  2 sigma2 w_q     sum_ab M_ab R_q,ab
+//   d loglik / d theta_qk = -  sigma2 w_q^2   sum_ab M_ab (x_ak - x_bk)^2 R_q,ab
+// over the lower 64 x 64 tiles of M (rinv_tile_kernel<true> left them where L was; zero beyond n); a tile off the diagonal
+// counts twice, a diagonal tile is summed whole (M and R_q are symmetric).  Shaped like cov_kernel, whose arithmetic it
+// repeats (R_q is regenerated from X, never stored): lane = row, a wave owns 16 columns, the column coordinates are
+// broadcast LDS reads, one component per pass with 1 + KG running sums per lane (d <= KG = 4, 6, 8; theta_qk = 0 beyond d
+// makes the padded dimensions vanish from the dot product).  Vector-issue bound like cov_kernel: ~38 instructions per
+// entry and component.  KG = 0: any d, run-time loops over the dimensions in groups of eight (the exp is recomputed per
+// group).  Partial sums per tile -> gpart[(matrix, tile)][P], summed by blocked_grad_reduce_kernel.
+struct GradContractArgs {
+  const double* A;       // M tiles (lower), column-major with leading dimension ld
+  size_t a_stride;
+  int ld, n, d, K;
+  const double* X;       // n x d
+  const double* params;
+  int ldp, draw0;
+  double* gpart;         // nb x ntiles64 x P
+  int ntiles64;
+};
+
+size_t grad_contract_lds(int d, int K) {
+  return sizeof(double) * ((size_t)kExpTableDoubles + (size_t)(2 * d + 2 * K) * 64 + (size_t)K * d + 4 * (size_t)(K + K * d));
+}
+
+template <int KG>
+__global__ __launch_bounds__(256, (KG == 4 || KG == 6) ? 4 : 3) void grad_contract_kernel(GradContractArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int G = KG > 0 ? KG : 8;
+  const int d = a.d, K = a.K, Pn = K + K * d, n = a.n;
+  double* etab = smem;
+  double* xa = etab + kExpTableDoubles;   // [d][64]
+  double* xb = xa + d * 64;               // [d][64]
+  double* ua = xb + d * 64;               // [K][64]
+  double* ub = ua + K * 64;               // [K][64]
+  double* th = ub + K * 64;               // [K][d]
+  double* part = th + K * d;              // [4][Pn]
+  const int t = blockIdx.x, b = blockIdx.z, gdraw = a.draw0 + b;
+  int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  while (tr * (tr + 1) / 2 > t) --tr;
+  const int tc = t - tr * (tr + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = tr * 64, j0 = tc * 64, jl0 = wave * 16;
+
+  // this lane's 16 entries of M first: the only HBM reads of the kernel, in flight during the prologue
+  const double* Mt = a.A + (size_t)b * a.a_stride + (size_t)(i0 + lane) + (size_t)(j0 + jl0) * a.ld;
+  double m[16];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ga = ta * kTile + row0 + y * 16 + l15, gb = tb * kTile + col0 + x * 16 + l4 + 4 * r;
-          if (ga < n && gb < n) {
-            out[ga + (size_t)gb * n] = acc[x][y][r];
-            out[gb + (size_t)ga * n] = acc[x][y][r];
-          }
-        }
-    return;
-  } else {
-    const int d = g.d, K = g.K, Pn = K + K * d;
-    const int gdraw = g.draw0 + b;
-    // the staging LDS is free (the K loop ended on a barrier)
-    double* xa = smem;                 // [d][128]
-    double* xb = xa + d * kTile;       // [d][128]
-    double* ua = xb + d * kTile;       // [K][128]
-    double* ub = ua + K * kTile;       // [K][128]
-    double* al_a = ub + K * kTile;     // [128]
-    double* al_b = al_a + kTile;       // [128]
-    double* th = al_b + kTile;         // [K][d]
-    double* w2 = th + K * d;           // [K]
-    double* part = w2 + K;             // [4][Pn]
-    double* etab = part + 4 * Pn;      // 2^(j/256) for exp_cov
-    exp_table_load(etab, tid, 256);
-    for (int e = tid; e < K * d; e += 256) th[e] = g.params[gdraw + (size_t)(K + e) * g.ldp];
-    if (tid < K) { const double w = g.params[gdraw + (size_t)tid * g.ldp]; w2[tid] = w * w; }
-    for (int e = tid; e < d * kTile; e += 256) {
-      const int k = e / kTile, r = e % kTile;
-      const int ga = ta * kTile + r, gb = tb * kTile + r;
-      xa[e] = ga < n ? g.X[ga + (size_t)k * n] : 0.0;
-      xb[e] = gb < n ? g.X[gb + (size_t)k * n] : 0.0;
+  for (int jj = 0; jj < 16; ++jj) m[jj] = Mt[(size_t)jj * a.ld];
+
+  exp_table_load(etab, tid, 256);
+  for (int e = tid; e < K * d; e += 256) th[e] = a.params[gdraw + (size_t)(K + e) * a.ldp];
+  for (int e = tid; e < d * 64; e += 256) {
+    const int k = e >> 6, r = e & 63;
+    xa[e] = i0 + r < n ? a.X[i0 + r + (size_t)k * n] : 0.0;
+    xb[e] = j0 + r < n ? a.X[j0 + r + (size_t)k * n] : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < K * 64; e += 256) {
+    const int q = e >> 6, r = e & 63;
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double tq = th[q * d + k], va = xa[k * 64 + r], vb = xb[k * 64 + r];
+      sa = fma(va * va, tq, sa);
+      sb = fma(vb * vb, tq, sb);
     }
-    if (tid < kTile) {
-      al_a[tid] = g.alpha[(size_t)b * g.npad + ta * kTile + tid];
-      al_b[tid] = g.alpha[(size_t)b * g.npad + tb * kTile + tid];
-    }
-    __syncthreads();
-    for (int e = tid; e < K * kTile; e += 256) {
-      const int q = e / kTile, r = e % kTile;
-      double sa = 0.0, sb = 0.0;
-      for (int k = 0; k < d; ++k) {
-        const double tq = th[q * d + k], va = xa[k * kTile + r], vb = xb[k * kTile + r];
-        sa += va * va * tq;
-        sb += vb * vb * tq;
+    ua[e] = sa;
+    ub[e] = sb;
+  }
+  __syncthreads();
+
+  for (int q = 0; q < K; ++q) {
+    const double ur = ua[q * 64 + lane];
+    for (int k0 = 0; k0 < (KG > 0 ? 1 : d); k0 += G) {
+      double xav[G], xr[G], hs[G], gs = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < G; ++kk) {
+        const int k = k0 + kk;
+        xav[kk] = xa[(k < d ? k : d - 1) * 64 + lane];
+        // the squared differences do not depend on the component: unpinned, those of all 16 columns are computed before
+        // the loop over the components and kept (16 KG doubles per lane: scratch)
+        asm volatile("" : "+v"(xav[kk]));
+        xr[kk] = k < d ? xav[kk] * th[q * d + k] : 0.0;
+        hs[kk] = 0.0;
       }
-      ua[e] = sa;
-      ub[e] = sb;
-    }
-    __syncthreads();
-    double sw = 0.0;
-    for (int q = 0; q < K; ++q) sw += w2[q];
-    const double cs = g.sigma2 * sw;
-    const double sym = ta == tb ? 1.0 : 2.0;   // lower tiles only: off-diagonal tiles count twice
-    // M in place of the accumulators (zero outside the n x n matrix)
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+      for (int jj = 0; jj < 16; ++jj) {
+        const int c = jl0 + jj;
+        double sdot = 0.0, dfsq[G];
 #pragma unroll
-      for (int y = 0; y < 4; ++y)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int lr = row0 + y * 16 + l15, lc = col0 + x * 16 + l4 + 4 * r;
-          const int ga = ta * kTile + lr, gb = tb * kTile + lc;
-          const double m = 0.5 * (al_a[lr] * al_b[lc] / (cs * cs) - acc[x][y][r] / cs);
-          acc[x][y][r] = (ga < n && gb < n) ? sym * m : 0.0;
+        for (int kk = 0; kk < G; ++kk) {
+          const int k = k0 + kk;
+          const double xbv = xb[(k < d ? k : d - 1) * 64 + c];
+          const double df = xav[kk] - xbv;
+          dfsq[kk] = df * df;
+          if (KG > 0) sdot = fma(xr[kk], xbv, sdot);
         }
-    for (int q = 0; q < K; ++q) {
-      d4 T[4][4];   // M .* R_q
-      double gsum = 0.0;
+        if (KG == 0)
+          for (int k = 0; k < d; ++k) sdot = fma(xa[k * 64 + lane] * th[q * d + k], xb[k * 64 + c], sdot);
+        const double dist = fma(-2.0, sdot, ur + ub[q * 64 + c]);
+        const double v = m[jj] * exp_cov(dist, etab);
+        gs += v;
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+        for (int kk = 0; kk < G; ++kk) {
+          hs[kk] = fma(v, dfsq[kk], hs[kk]);
+          // pinned: the running sums are only read after the loop, so left alone their FMAs are sunk below all 16 exp
+          // chains -- with the 16 values and 16 KG column coordinates they need kept in scratch until then
+          asm volatile("" : "+v"(hs[kk]));
+        }
+      }
+      if (k0 == 0) {
+        for (int off = 32; off > 0; off >>= 1) gs += __shfl_down(gs, off, 64);
+        if (lane == 0) part[wave * Pn + q] = gs;
+      }
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int lr = row0 + y * 16 + l15, lc = col0 + x * 16 + l4 + 4 * r;
-            double sdot = 0.0;
-            for (int k = 0; k < d; ++k) sdot = fma(xa[k * kTile + lr] * th[q * d + k], xb[k * kTile + lc], sdot);
-            const double dist = (ua[q * kTile + lr] + ub[q * kTile + lc]) + (-2.0 * sdot);
-            const double v = acc[x][y][r] * exp_cov(dist, etab);
-            T[x][y][r] = v;
-            gsum += v;
-          }
-      for (int off = 32; off > 0; off >>= 1) gsum += __shfl_down(gsum, off, 64);
-      if (lane == 0) part[wave * Pn + q] = gsum;
-      for (int k = 0; k < d; ++k) {
-        double hsum = 0.0;
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 4; ++y)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int lr = row0 + y * 16 + l15, lc = col0 + x * 16 + l4 + 4 * r;
-              const double df = xa[k * kTile + lr] - xb[k * kTile + lc];
-              hsum = fma(T[x][y][r], df * df, hsum);
-            }
-        for (int off = 32; off > 0; off >>= 1) hsum += __shfl_down(hsum, off, 64);
-        if (lane == 0) part[wave * Pn + K + q * d + k] = hsum;
+      for (int kk = 0; kk < G; ++kk) {
+        double v = hs[kk];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && k0 + kk < d) part[wave * Pn + K + q * d + k0 + kk] = v;
       }
     }
-    __syncthreads();
-    if (tid < Pn)
-      g.gpart[((size_t)b * ntiles + t) * Pn + tid] =
-          (part[tid] + part[Pn + tid]) + (part[2 * Pn + tid] + part[3 * Pn + tid]);
+  }
+  __syncthreads();
+  if (tid < Pn) {
+    const double sym = tr == tc ? 1.0 : 2.0;
+    a.gpart[((size_t)b * a.ntiles64 + t) * Pn + tid] =
+        sym * ((part[tid] + part[Pn + tid]) + (part[2 * Pn + tid] + part[3 * Pn + tid]));
   }
 }
 
@@ -1531,12 +1632,15 @@ struct GradReduceArgs {
   double* grad;
 };
 
-__global__ void blocked_grad_reduce_kernel(GradReduceArgs g) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= g.nb * g.P) return;
-  const int b = idx / g.P, q = idx % g.P, gb = g.b0 + b;
+// one workgroup per (matrix, parameter): 256 strided partial sums, then the block's fixed-order tree (round 4; before, ONE
+// thread walked a parameter's 528 -- now 2080 -- partials: 0.9 ms for 16 draws at n = 4096, as long as the contraction itself)
+__global__ __launch_bounds__(256) void blocked_grad_reduce_kernel(GradReduceArgs g) {
+  __shared__ double red[4];
+  const int b = blockIdx.x / g.P, q = blockIdx.x % g.P, gb = g.b0 + b, tid = threadIdx.x;
   double s = 0.0;
-  for (int t = 0; t < g.ntiles; ++t) s += g.gpart[((size_t)b * g.ntiles + t) * g.P + q];
+  for (int t = tid; t < g.ntiles; t += 256) s += g.gpart[((size_t)b * g.ntiles + t) * g.P + q];
+  s = block_sum(s, red, tid);
+  if (tid) return;
   const int c = q < g.K ? q : (q - g.K) / g.d;
   const double wc = g.params[gb + (size_t)c * g.ldp];
   double v = q < g.K ? 2.0 * g.sigma2 * wc * s : -g.sigma2 * wc * wc * s;
@@ -1696,6 +1800,7 @@ struct GroupRun {
       const int ntiles = nt * (nt + 1) / 2;
       RinvArgs ra{};
       ra.A = w.A; ra.a_stride = w.a_stride; ra.npad = npad; ra.ld = w.ld; ra.nt = nt; ra.n = n; ra.nb = nb;
+      ra.wide = h->opt_wide_offsets;
       const dim3 grid(round_up(nb, 8) * ntiles), block(256);
       if (job->kind == kJobInverse) {
         ra.Rinv = job->Rinv;
@@ -1703,13 +1808,21 @@ struct GroupRun {
       } else {
         const int P = dv.K + dv.K * d;
         AlphaArgs aa{w.A, w.a_stride, npad, w.ld, n, w.fin + nb, job->alpha};
-        hipLaunchKernelGGL(alpha_kernel, dim3((npad + 255) / 256, nb), dim3(256), 0, s, aa);
+        hipLaunchKernelGGL(alpha_kernel, dim3(npad / 64, nb), dim3(256), 0, s, aa);
         ra.X = X; ra.d = d; ra.K = dv.K; ra.params = dv.params; ra.ldp = dv.ldp; ra.draw0 = b0;
         ra.sigma2 = sigma2; ra.alpha = job->alpha; ra.gpart = job->gpart;
         hipLaunchKernelGGL(rinv_tile_kernel<true>, grid, block, gemm_lds_bytes<1>(), s, ra);
-        GradReduceArgs ga{job->gpart, ntiles, P, dv.K, d, nb, b0, job->Btot, dv.params, dv.ldp, sigma2,
+        const int nt64 = npad / 64, ntg = nt64 * (nt64 + 1) / 2;
+        GradContractArgs ca{w.A, w.a_stride, w.ld, n, d, dv.K, X, dv.params, dv.ldp, b0, job->gpart, ntg};
+        const dim3 cgrid(ntg, 1, nb);
+        const size_t clds = grad_contract_lds(d, dv.K);
+        if (d <= 4) hipLaunchKernelGGL(grad_contract_kernel<4>, cgrid, block, clds, s, ca);
+        else if (d <= 6) hipLaunchKernelGGL(grad_contract_kernel<6>, cgrid, block, clds, s, ca);
+        else if (d <= 8) hipLaunchKernelGGL(grad_contract_kernel<8>, cgrid, block, clds, s, ca);
+        else hipLaunchKernelGGL(grad_contract_kernel<0>, cgrid, block, clds, s, ca);
+        GradReduceArgs ga{job->gpart, ntg, P, dv.K, d, nb, b0, job->Btot, dv.params, dv.ldp, sigma2,
                           status, job->grad};
-        hipLaunchKernelGGL(blocked_grad_reduce_kernel, dim3((nb * P + 255) / 256), dim3(256), 0, s, ga);
+        hipLaunchKernelGGL(blocked_grad_reduce_kernel, dim3(nb * P), dim3(256), 0, s, ga);
       }
     }
   }
@@ -1724,11 +1837,11 @@ struct GroupRun {
   }
 };
 
-// LDS scratch of the gradient contraction must fit the S = 1 staging area
-bool blocked_grad_supported(int d, int K) {
-  return sizeof(double) * ((size_t)(2 * d + 2 * K + 2) * kTile + (size_t)K * d + K + 4 * (K + K * d) + kExpTableDoubles) <=
-         gemm_lds_bytes<1>();
-}
+// LDS of the gradient contraction (grad_contract_kernel) must fit a workgroup's share
+bool blocked_grad_supported(int d, int K) { return grad_contract_lds(d, K) <= (size_t)kLdsBytes - 64; }
+
+// partial sums of the gradient contraction per matrix: one per lower 64 x 64 tile
+size_t blocked_grad_partials(int npad) { const size_t nt64 = (size_t)npad / 64; return nt64 * (nt64 + 1) / 2; }
 
 void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double* y, DrawView dv,
                     int b0, int nb, int npad, double sigma2, int mean_mode, double tau2,
@@ -1741,6 +1854,10 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
     raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
     raise_lds_limit((const void*)rinv_tile_kernel<false>, "rinv_tile_kernel<false>");
     raise_lds_limit((const void*)rinv_tile_kernel<true>, "rinv_tile_kernel<true>");
+    raise_lds_limit((const void*)grad_contract_kernel<4>, "grad_contract_kernel<4>");
+    raise_lds_limit((const void*)grad_contract_kernel<6>, "grad_contract_kernel<6>");
+    raise_lds_limit((const void*)grad_contract_kernel<8>, "grad_contract_kernel<8>");
+    raise_lds_limit((const void*)grad_contract_kernel<0>, "grad_contract_kernel<0>");
   });
   GroupRun r{};
   r.h = h; r.s = h->stream; r.X = X; r.n = n; r.d = d; r.y = y; r.dv = dv; r.b0 = b0; r.nb = nb;

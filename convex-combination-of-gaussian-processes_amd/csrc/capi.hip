@@ -861,12 +861,13 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   CCGP_HIP(hipSetDevice(h->device));
   const int P = K + K * d;
   if (n > kSmallMaxN || small_lds_bytes(n, d, 1) > (size_t)kLdsBytes - 64) {
-    // blocked path: identity rows ride along as extra tile rows, then R^-1 tiles are formed in
-    // registers and contracted with the kernel derivatives (blocked.hip, rinv_tile_kernel)
+    // blocked path: identity rows ride along as extra tile rows, then the tiles of R^-1 are formed (rinv_tile_kernel), turned
+    // into M and contracted with the kernel derivatives (grad_contract_kernel; blocked.hip)
     if (!blocked_grad_supported(d, K))
       return fail(h, CCGP_EUNSUPPORTED, "ccgp_loglik_grad_batch: d + K too large for the contraction kernel's LDS");
-    const int npad = round_up(n, kTile), nt = npad / kTile, ne = nt, ntiles = nt * (nt + 1) / 2;
-    const size_t per_extra = sizeof(double) * ((size_t)ntiles * P + npad);
+    const int npad = round_up(n, kTile), nt = npad / kTile, ne = nt;
+    const size_t ntiles = blocked_grad_partials(npad);
+    const size_t per_extra = sizeof(double) * (ntiles * P + npad);
     size_t per = blocked_ws_bytes(npad, 1, ne) + per_extra;
     size_t glimit = h->ws_limit, gfree = 0, gtotal = 0;
     if (hipMemGetInfo(&gfree, &gtotal) == hipSuccess) {

@@ -186,10 +186,11 @@ struct BlockedJob {
   // kJobGrad: d loglik / d params; grad is Btot x P column-major
   double* grad;
   int Btot;
-  double* gpart;        // scratch: nb x ntiles x P partial sums
+  double* gpart;        // scratch: nb x blocked_grad_partials(npad) x P partial sums
   double* alpha;        // scratch: nb x npad,  R^-1 (y - beta 1)
 };
 bool blocked_grad_supported(int d, int K);
+size_t blocked_grad_partials(int npad);   // partial sums per matrix and parameter (gpart = nb x this x P)
 size_t blocked_ws_bytes(int npad, int nb, int ne);
 BlockedWs blocked_carve(void* ws, int npad, int nb, int ne);
 // factorise nb matrices in place and finish the likelihood; loglik/beta/status are

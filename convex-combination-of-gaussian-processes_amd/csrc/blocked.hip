@@ -1307,20 +1307,38 @@ struct PredFinishArgs {
   double* var;
 };
 
-__global__ __launch_bounds__(256) void predict_finish_kernel(PredFinishArgs g) {
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= g.m) return;
+// A workgroup owns 64 test sites (lane = site: a column of the rows L^-1 r(x_t) is 512 contiguous bytes per wave), its 16
+// waves take the columns c = w, w + 16, ...; three running sums per lane, combined in LDS in fixed order.  (Rounds 1 - 3:
+// one thread per site walking all n columns alone -- 1.2 ms for 16 draws x 128 sites at n = 4096, a tenth of the call.)
+constexpr int kPredFinishWaves = 16;
+__global__ __launch_bounds__(64 * kPredFinishWaves) void predict_finish_kernel(PredFinishArgs g) {
+  __shared__ double part[3][kPredFinishWaves][64];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = blockIdx.x * 64 + lane;
   const double* Ab = g.A + (size_t)b * g.a_stride;
   const double* zrow = Ab + g.npad;
-  const double* wrow = g.E ? g.E + (size_t)b * g.e_stride + t : Ab + g.npad + kTile + t;
+  const int tc = t < g.m ? t : g.m - 1;   // lanes beyond m read a valid row and write nothing
+  const double* wrow = g.E ? g.E + (size_t)b * g.e_stride + tc : Ab + g.npad + kTile + tc;
   const int ldw = g.E ? g.lde : g.ld;
   double ww = 0.0, z1w = 0.0, zyw = 0.0;
-  for (int c = 0; c < g.n; ++c) {
+#pragma unroll 4
+  for (int c = wave; c < g.n; c += kPredFinishWaves) {
     const double w = wrow[(size_t)c * ldw];
     ww = fma(w, w, ww);
     z1w = fma(zrow[1 + (size_t)c * g.ld], w, z1w);
     zyw = fma(zrow[(size_t)c * g.ld], w, zyw);
+  }
+  part[0][wave][lane] = ww;
+  part[1][wave][lane] = z1w;
+  part[2][wave][lane] = zyw;
+  __syncthreads();
+  if (tid >= 64 || t >= g.m) return;
+  ww = z1w = zyw = 0.0;
+  for (int w = 0; w < kPredFinishWaves; ++w) {
+    ww += part[0][w][lane];
+    z1w += part[1][w][lane];
+    zyw += part[2][w][lane];
   }
   const double beta = g.beta[b], s11 = g.s11[b];
   double mean = beta + (zyw - beta * z1w);
@@ -1792,7 +1810,7 @@ struct GroupRun {
       if (pr) {
         PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, pr->m, nullptr, 0, 0, w.fin, w.fin + nb, status, b0, pr->S,
                           sigma2, pr->mean, pr->var};
-        hipLaunchKernelGGL(predict_finish_kernel, dim3((pr->m + 255) / 256, nb), dim3(256), 0, s, pa);
+        hipLaunchKernelGGL(predict_finish_kernel, dim3((pr->m + 63) / 64, nb), dim3(64 * kPredFinishWaves), 0, s, pa);
       }
     }
     if (job && job->kind >= kJobInverse) {
@@ -1915,7 +1933,7 @@ void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int
   ScopedTimer t(h, CCGP_T_SOLVE, s);
   PredFinishArgs pa{g.A, w.a_stride, npad, w.ld, n, m, E, e_stride, lde, w.fin + s0, w.fin + S + s0, status, s0, S,
                     sigma2, mean, var};
-  hipLaunchKernelGGL(predict_finish_kernel, dim3((m + 255) / 256, ns), dim3(256), 0, s, pa);
+  hipLaunchKernelGGL(predict_finish_kernel, dim3((m + 63) / 64, ns), dim3(64 * kPredFinishWaves), 0, s, pa);
 }
 
 }  // namespace ccgp

@@ -424,6 +424,38 @@ def test_blocked_path_gradient_and_inverse(handle):
         np.testing.assert_allclose(r["R_Inv"], want["R_inv"], rtol=1e-7, atol=1e-8 * np.abs(want["R_inv"]).max())
 
 
+@pytest.mark.parametrize("n,d,K", [(200, 8, 2), (150, 11, 3), (260, 1, 4), (300, 6, 1), (140, 20, 2)])
+def test_blocked_gradient_contraction_instances(handle, n, d, K):
+    """grad_contract_kernel is instantiated for d <= 4, 6, 8 (straight-line contraction, theta = 0 on the padded dimensions)
+    and for any d (groups of eight dimensions, the exp recomputed per group); one component per pass, so any K.  Every
+    instance against central differences of the device log-likelihood in every coordinate, ragged n (padding rows of M are
+    zero), and a failing draw (NaN gradient, status set)."""
+    X, y = synthetic_design(n, d, seed=11 * n + d)
+    rng = np.random.default_rng(n + d + K)
+    rough = 2.0 * n ** (2.0 / d) / d
+    rows = np.empty((3, K + K * d))
+    for b in range(3):
+        th = np.exp(rng.uniform(np.log(0.02 * rough), np.log(0.3 * rough), size=(K, d)))
+        th[-1] = rng.uniform(rough, 2.0 * rough, d)
+        rows[b] = np.concatenate([0.2 + 0.6 * rng.dirichlet(np.ones(K)), th.ravel()])
+    rows[2, K:] = 0.0                                  # R = 11': fails
+    ll, beta, grad, st = handle.loglik_grad_batch(X, y, K, rows, 1.3)
+    assert st[0] == 0 and st[1] == 0 and st[2] != 0 and np.isnan(grad[2]).all() and np.isfinite(grad[:2]).all()
+    ll0, _, _ = handle.loglik_batch(X, y, K, rows, 1.3)
+    np.testing.assert_array_equal(ll[:2], ll0[:2])     # the sweep with identity rows gives the same likelihood bits
+    P = rows.shape[1]
+    for b in range(2):
+        pert = np.repeat(rows[b][None], 2 * P, axis=0)
+        hstep = 1e-5 * np.abs(rows[b])
+        for j in range(P):
+            pert[2 * j, j] += hstep[j]
+            pert[2 * j + 1, j] -= hstep[j]
+        llp, _, stp = handle.loglik_batch(X, y, K, pert, 1.3)
+        assert not stp.any()
+        fd = (llp[0::2] - llp[1::2]) / (2 * hstep)
+        np.testing.assert_allclose(grad[b], fd, rtol=2e-4, atol=2e-4 * np.abs(fd).max(), err_msg="n=%d d=%d K=%d" % (n, d, K))
+
+
 def test_gradient_at_n4096_matches_central_differences_of_the_device_likelihood(handle):
     """Full BASELINE config 4 size: the analytic gradient (identity rows + R^-1 contraction)
     against central differences of the device log-likelihood itself, every coordinate."""

@@ -1232,6 +1232,7 @@ struct FinishArgs {
   int ld;
   double* s11_out;   // nb doubles (1' R^-1 1 in the factor's metric), for the prediction pass
   double* beta_out;  // nb doubles, chunk-local copy of beta
+  double* logdet_out;   // log det of the factorised matrix (mode 0: the normalised R), indexed like loglik; or nullptr
 };
 
 __device__ inline double block_sum(double v, double* red, int tid) {
@@ -1284,6 +1285,7 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs g) {
     if (g.loglik) g.loglik[gb] = ll;
     if (g.beta) g.beta[gb] = beta;
     if (g.s11_out) g.s11_out[b] = s11;
+    if (g.logdet_out) g.logdet_out[gb] = (g.status && g.status[gb] != 0) ? kNaN : logdet;
     if (g.beta_out) g.beta_out[b] = beta;
   }
 }
@@ -1806,6 +1808,7 @@ struct GroupRun {
       fa.ldp = dv.ldp; fa.K = dv.K; fa.b0 = b0; fa.nt = nt; fa.n = n; fa.sigma2 = sigma2;
       fa.mode = mean_mode; fa.loglik = loglik; fa.beta = beta; fa.status = status; fa.ld = w.ld;
       fa.s11_out = w.fin; fa.beta_out = w.fin + nb;
+      fa.logdet_out = job && job->kind == kJobLogdet ? job->logdet : nullptr;
       hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, s, fa);
       if (pr) {
         PredFinishArgs pa{w.A, w.a_stride, npad, w.ld, n, pr->m, nullptr, 0, 0, w.fin, w.fin + nb, status, b0, pr->S,

@@ -1105,10 +1105,47 @@ int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, in
     return fail(h, CCGP_EINVAL, "ccgp_mixed_logdet_designs: bad argument");
   if (h->fam.id != 0)
     return fail(h, CCGP_EUNSUPPORTED, "ccgp_mixed_logdet_designs: Gaussian family only (BSQ:856-877)");
-  if (!small_reg_supported(n, d, K, true))
-    return fail(h, CCGP_EUNSUPPORTED, "ccgp_mixed_logdet_designs: designs of more than 128 points (or too wide for LDS) not implemented");
   CCGP_HIP(hipSetDevice(h->device));
   const int P = K + K * d;
+  if (!small_reg_supported(n, d, K, true)) {
+    // more than 128 points (or too wide for the register-resident evaluator): the blocked sweep, one design at a time --
+    // its chunk shares ONE design among its matrices, and here every matrix has its own.  The reference's candidate
+    // sets are small (BSQ:856-877: a few dozen points); this branch exists so that the entry point has no size limit.
+    const int npad = round_up(n, kTile);
+    size_t need = Carver::al(sizeof(double) * (size_t)B * n * d) + Carver::al(sizeof(double) * n) + Carver::al(sizeof(double) * P) +
+                  3 * Carver::al(sizeof(double) * B) + Carver::al(sizeof(int) * (size_t)B);
+    int rc = ensure_stage(h, need);
+    if (rc) return rc;
+    rc = ensure_ws(h, blocked_ws_bytes(npad, 1, 0) + 512);
+    if (rc) return rc;
+    Carver c(h->stage);
+    double* dXs = c.take<double>((size_t)B * n * d);
+    double* dy = c.take<double>(n);
+    double* dp = c.take<double>(P);
+    double* dld = c.take<double>(B);
+    double* dll = c.take<double>(B);
+    double* dbeta = c.take<double>(B);
+    int* dst = c.take<int>(B);
+    if (int prc = push(h, {piece(dXs, Xs, (size_t)B * n * d), piece(dp, params, P)})) return prc;
+    CCGP_HIP(hipMemsetAsync(dy, 0, sizeof(double) * n, h->stream));
+    CCGP_HIP(hipMemsetAsync(dst, 0, sizeof(int) * (size_t)B, h->stream));
+    DrawView dv{dp, 1, K, d};
+    dv.fam = h->fam;
+    if (int frc = check_family(h, dv.fam, d, K)) return frc;
+    BlockedWs w = blocked_carve(h->ws, npad, 1, 0);
+    for (int i = 0; i < B; ++i) {
+      BlockedJob job{};
+      job.kind = kJobLogdet;
+      job.logdet = dld + i;
+      blocked_loglik(h, dXs + (size_t)i * n * d, n, d, dy, dv, 0, 1, npad, 1.0, CCGP_MEAN_PROFILE_BETA, 0.0, w, dll + i,
+                     dbeta + i, dst + i, &job);
+    }
+    CCGP_LAUNCH_CHECK();
+    std::vector<int> st(B);
+    if (int prc = pull(h, {piece(dld, out_logdet, B), piece(dst, st.data(), B)})) return prc;
+    if (status) std::memcpy(status, st.data(), sizeof(int) * (size_t)B);
+    return count_bad(st.data(), B);
+  }
   size_t need = Carver::al(sizeof(double) * (size_t)B * n * d) + Carver::al(sizeof(double) * P) +
                 Carver::al(sizeof(double) * B) + Carver::al(sizeof(int) * (size_t)B);
   int rc = ensure_stage(h, need);

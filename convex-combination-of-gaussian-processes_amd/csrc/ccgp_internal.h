@@ -173,7 +173,7 @@ struct BlockedWs {
   int ne;           // extra full tile rows (ceil(m / 128) for prediction, else 0)
 };
 // optional extra work riding on a blocked sweep (n > 128)
-enum { kJobPredict = 1, kJobInverse = 2, kJobGrad = 3 };
+enum { kJobLogdet = -1, kJobPredict = 1, kJobInverse = 2, kJobGrad = 3 };   // >= kJobInverse: identity rows ride along
 struct BlockedJob {
   int kind;
   // kJobPredict (a10 + a11): m cross-correlation rows ride along as extra tile rows
@@ -188,6 +188,8 @@ struct BlockedJob {
   int Btot;
   double* gpart;        // scratch: nb x blocked_grad_partials(npad) x P partial sums
   double* alpha;        // scratch: nb x npad,  R^-1 (y - beta 1)
+  // kJobLogdet: log det of the normalised mixed correlation matrix (entropy criteria, BSQ:856-877), indexed like loglik
+  double* logdet;
 };
 bool blocked_grad_supported(int d, int K);
 size_t blocked_grad_partials(int npad);   // partial sums per matrix and parameter (gpart = nb x this x P)

@@ -244,7 +244,9 @@ int ccgp_predict_post(ccgp_handle* h, const double* Xnew, int m, const double* X
  * Augmented.Mixed.Entropy = -det(R.new - R.cross R.old^-1 R.cross') (same file :869-877), which by
  * the Schur complement equals -det(R.mixed(D.old U D.new)) / det(R.mixed(D.old)): both are log
  * determinants of the mixed correlation matrix of a CANDIDATE DESIGN.  Xs holds B designs of
- * n x d (column-major each, design b at Xs + b*n*d) that share ONE parameter row; n <= 128. */
+ * n x d (column-major each, design b at Xs + b*n*d) that share ONE parameter row.  Up to 128 points (the reference's
+ * candidate sets are a few dozen) all B designs are evaluated in one launch; larger designs run the blocked sweep one
+ * design at a time. */
 int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, int B, int K,
                               const double* params, double* out_logdet, int* status);
 

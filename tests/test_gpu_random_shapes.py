@@ -131,3 +131,62 @@ def test_kept_factors_and_design_logdets(handle, n, d, K, seed):
     for i in range(4):
         want = np.linalg.slogdet(orc.mixed_corr_matrix_general(designs[i], w, Th))[1]
         assert ld[i] == pytest.approx(want, rel=1e-8, abs=1e-7), (n, d, K, i)
+
+
+@pytest.mark.parametrize("n,nu,seed", [(7, 1.25, 1), (33, 1.5, 2), (64, 2.5, 3), (90, 5.0, 4), (128, 1.5, 5), (129, 2.5, 6),
+                                        (200, 7.5, 7), (300, 5.0, 8)])
+def test_matern_family_on_both_paths(handle, n, nu, seed):
+    """The 1-D scripts' Matern kernel (D1:348-351) through the batched likelihood and prediction, on the register-resident
+    evaluator (n <= 128) and on the blocked sweep; design points a jittered grid on [0, 1], length scales around the spacing
+    (smoother kernels on closer points are numerically singular at any precision)."""
+    from ccgp_amd import api
+    rng = np.random.default_rng(seed)
+    x = np.sort((np.arange(n) + rng.uniform(0.2, 0.8, n)) / n)[:, None]
+    y = np.sin(9.0 * x[:, 0]) + 0.3 * np.cos(31.0 * x[:, 0])
+    h = 1.0 / n
+    B = 4
+    P = np.column_stack([rng.uniform(0.3, 0.9, B), rng.uniform(0.1, 0.7, B), rng.uniform(1.5, 3.0, B) * h,
+                         rng.uniform(0.3, 0.8, B) * h])
+    Xt = rng.random((5, 1))
+    try:
+        handle.set_kernel(api.KERNEL_MATERN, nu)
+        ll, beta, st = handle.loglik_batch(x, y, 2, P, 1.7)
+        mean, var, beta2, st2 = handle.predict_batch(x, y, 2, P[:2], Xt, 1.7)
+    finally:
+        handle.set_kernel(api.KERNEL_GAUSS, 0.0)
+    assert not st.any() and not st2.any()
+    for b in range(B):
+        w = P[b, :2]
+        R = (w[0] ** 2 * orc.corr_matrix_matern(nu, x, P[b, 2]) + w[1] ** 2 * orc.corr_matrix_matern(nu, x, P[b, 3])) / np.sum(w ** 2)
+        cond = np.linalg.cond(R)
+        R_inv = orc.solve_inverse(R)
+        b_ = orc.beta_mle(R_inv, y)
+        want = orc.dmnorm_log(y, b_, 1.7 * np.sum(w ** 2) * R)
+        tol = max(1e-9, 100 * cond * np.finfo(float).eps)
+        assert ll[b] == pytest.approx(want, rel=tol), (n, nu, cond)
+        assert beta[b] == pytest.approx(b_, rel=10 * tol, abs=1e-9)
+        if b < 2:
+            mf, v1, v2 = orc.factors(R_inv, b_, y)
+            for t in range(5):
+                r = (w[0] ** 2 * orc.corr_vec_matern(Xt[t, 0], x, P[b, 2], nu) +
+                     w[1] ** 2 * orc.corr_vec_matern(Xt[t, 0], x, P[b, 3], nu)) / np.sum(w ** 2)
+                wm, wv = orc.predict_post_from_factors(r, b_, mf, v1, v2, R_inv, 1.7)
+                assert mean[b, t] == pytest.approx(wm, rel=10 * tol, abs=10 * tol)
+                assert var[b, t] == pytest.approx(wv, rel=100 * tol, abs=100 * tol * 1.7)
+
+
+@pytest.mark.parametrize("n,d,G,N,take_log,seed", [(12, 2, 5, 16, True, 1), (64, 4, 3, 33, True, 2), (100, 2, 4, 20, False, 3),
+                                                     (129, 3, 2, 9, True, 4), (260, 2, 3, 7, True, 5)])
+def test_hyperprior_grid_random_shapes(handle, n, d, G, N, take_log, seed):
+    """choose.hyperpars (HX:584-595 / ADV:588-599) for grids, node counts and designs other than the scripts' own: the
+    device builds the G x N draws (Halton nodes, inverse-gamma quantiles) and averages; the oracle walks the R loops."""
+    rng = np.random.default_rng(seed)
+    X, y = synthetic_design(n, d, seed)
+    s = n ** (2.0 / d) / d                                   # theta ~ s: correlation e^-1 at the typical spacing
+    hyper = np.column_stack([rng.uniform(3.0, 6.0, G), rng.uniform(0.3, 0.8, G) * s * 4.0,
+                             rng.uniform(3.0, 6.0, G), rng.uniform(2.0, 5.0, G) * s * 4.0])
+    tau = 7.0
+    vals, arg = handle.grid_marginal(X, y, 1.3, hyper, N, tau, take_log)
+    want_arg, want = orc.choose_hyperpars(X, y, hyper, 1.3, N, tau, take_log)
+    np.testing.assert_allclose(vals, want, rtol=1e-8)
+    assert arg == want_arg                                    # 0-based row (the R shim adds the 1)

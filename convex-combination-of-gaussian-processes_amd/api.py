@@ -84,6 +84,7 @@ SIGNATURES = {
                                          c_double, _dp, _dp, _dp, _ip]),
     "ccgp_enable_timing": (c_int, [c_void_p, c_int]),
     "ccgp_get_timing": (c_int, [c_void_p, c_int, _dp, _ip]),
+    "ccgp_last_sweep_plan": (c_int, [c_void_p, _ip, _ip]),
 }
 
 _bound = None
@@ -339,6 +340,13 @@ class Handle:
             self._chk(lib().ccgp_get_timing(self._h, i, ctypes.byref(ms), ctypes.byref(cnt)))
             out[name] = (ms.value, cnt.value)
         return out
+
+    def last_sweep_plan(self):
+        """(block columns whose update generated its covariance tiles, 64 x 64 tiles per matrix left to cov_kernel) of the
+        last blocked sweep."""
+        g, t = c_int(), c_int()
+        self._chk(lib().ccgp_last_sweep_plan(self._h, ctypes.byref(g), ctypes.byref(t)))
+        return g.value, t.value
 
     # -- a1..a5 -------------------------------------------------------------------------
     def corr_matrix(self, X, theta):

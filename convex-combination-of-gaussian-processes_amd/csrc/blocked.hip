@@ -1674,7 +1674,7 @@ size_t blocked_ws_bytes(int npad, int nb, int ne) {
   const int nt = npad / kTile;
   size_t dbl = (size_t)nb * (npad + kTile * (1 + ne)) * npad + (size_t)nb * nt * kTile * kTile +
                (size_t)nb * (nt + 2) + 64 + (size_t)npad * kMaxD + 16 +
-               (size_t)nb * kMaxK * npad + ((size_t)(npad / 64) * (npad / 64) + 2 + 1) / 2 + 16;   // upad, tlist
+               (size_t)nb * kMaxK * npad + 16;   // upad
   return dbl * sizeof(double);
 }
 
@@ -1690,7 +1690,6 @@ BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
   w.fin = w.z + (size_t)nb * nt;
   w.xpad = w.fin + (((size_t)2 * nb + 15) & ~(size_t)15);   // 128-byte aligned: whole s_load_dwordx16 lines
   w.upad = w.xpad + (size_t)npad * kMaxD;
-  w.tlist = reinterpret_cast<int*>(w.upad + (size_t)nb * kMaxK * npad);
   return w;
 }
 
@@ -1723,6 +1722,7 @@ struct GroupRun {
   // A column is fused when every one of its tiles below the diagonal runs through update_tile_il: Gaussian family, whole
   // tiles (no strip option, no tail of ring strips in that launch: their epilogue has another lane layout), 32-bit
   // buffer offsets, and the epilogue's LDS image within the k-loop's 64 KiB.
+  bool any_fused = false;
   int plan_fusion() {
     fused.assign(nt, 0);
     const int nb8 = round_up(nb, 8), nfull = n / kTile;
@@ -1734,6 +1734,9 @@ struct GroupRun {
       const bool whole = !h->opt_tail_strips || update_tail(nb8, tiles) == 0;
       fused[j] = whole && ((size_t)j * kTile + 32) * (size_t)w.ld * 8 < 0xFFFF0000ull;   // fits_buffer_offsets(j * 128, ld)
     }
+    any_fused = false;
+    for (int j = 1; j < nt; ++j) any_fused = any_fused || fused[j];
+    if (!any_fused) return 0;   // cov_kernel enumerates every lower tile itself: no list
     h->tlist_host.clear();
     const int nt64 = npad / 64;
     for (int tr = 0; tr < nt64; ++tr)
@@ -1752,9 +1755,34 @@ struct GroupRun {
     {
       ScopedTimer t(h, CCGP_T_COV, s);
       const int ntl = plan_fusion();
-      (void)hipMemcpyAsync(w.tlist, h->tlist_host.data(), sizeof(int) * 2 * (size_t)ntl, hipMemcpyHostToDevice, s);
+      const int* tlist = nullptr;
+      if (any_fused) {
+        // the list lives in a buffer of the handle's own (nothing else writes it) and depends on the shapes only: a caller
+        // that repeats them (a grid per step, Metro) uploads it once
+        if (h->tlist_cap < (size_t)ntl) {
+          if (h->tlist_dev) (void)hipFree(h->tlist_dev);
+          h->tlist_dev = nullptr;
+          h->tlist_cap = 0;
+          h->tlist_key.clear();
+          if (hipMalloc(&h->tlist_dev, sizeof(int) * 2 * (size_t)ntl) == hipSuccess) h->tlist_cap = (size_t)ntl;
+        }
+        if (h->tlist_cap < (size_t)ntl) {          // no list, no fusion: cov_kernel writes every tile
+          any_fused = false;
+          fused.assign(nt, 0);
+        } else {
+          const std::vector<long long> key{npad, n, nb, w.ne, h->opt_tail_strips, d, dv.K, ntl};
+          if (key != h->tlist_key) {
+            (void)hipMemcpyAsync(h->tlist_dev, h->tlist_host.data(), sizeof(int) * 2 * (size_t)ntl, hipMemcpyHostToDevice, s);
+            h->tlist_key = key;
+          }
+          tlist = h->tlist_dev;
+        }
+      }
+      h->plan_gen_columns = 0;
+      for (int j = 1; j < nt; ++j) h->plan_gen_columns += fused[j];
+      h->plan_cov_tiles = tlist ? ntl : (npad / 64) * (npad / 64 + 1) / 2;
       launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld, w.xpad, w.upad,
-                       w.tlist, ntl);
+                       tlist, ntl);
       RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
       hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad / 16, nb), dim3(256), 0, s, ra);
       if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site

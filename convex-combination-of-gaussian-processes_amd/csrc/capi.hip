@@ -490,6 +490,7 @@ int ccgp_destroy(ccgp_handle* h) try {
     (void)hipEventDestroy(s.e1);
   }
   if (h->ws) (void)hipFree(h->ws);
+  if (h->tlist_dev) (void)hipFree(h->tlist_dev);
   if (h->stage) (void)hipFree(h->stage);
   if (h->pin) (void)hipHostFree(h->pin);
   for (auto& e : h->pull_ev)
@@ -605,6 +606,13 @@ int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches) t
   }
   if (out_ms) *out_ms = ms;
   if (out_launches) *out_launches = cnt;
+  return CCGP_OK;
+} CCGP_GUARD_END(h)
+
+int ccgp_last_sweep_plan(ccgp_handle* h, int* out_generating_columns, int* out_cov_tiles) try {
+  if (!h) return CCGP_EINVAL;
+  if (out_generating_columns) *out_generating_columns = h->plan_gen_columns;
+  if (out_cov_tiles) *out_cov_tiles = h->plan_cov_tiles;
   return CCGP_OK;
 } CCGP_GUARD_END(h)
 
@@ -1010,7 +1018,7 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   if ((out_Rinv ? reg_inv : reg_val) && ensure_pin(h, sizeof(double) * (in_d + out_d)) == CCGP_OK) {
     // The sequential caller's path (Metro evaluates ONE proposal per logpost call, HX:505-512): latency, not
     // throughput.  Inputs are packed into a pinned host buffer and cross PCIe in ONE copy, the results (log-lik,
-    // beta, status[, R^-1]) come back in one: 300 -> ~100 us per call with R.Inv at n = 64, 113 -> ~60 us without.
+    // beta, status[, R^-1]) come back in one: 300 -> ~100 us per call with R.Inv at n = 64, 113 -> ~60 us without (round 2).
     int rc2 = ensure_stage(h, Carver::al(sizeof(double) * in_d) + Carver::al(sizeof(double) * out_d) + 256);
     if (rc2) return rc2;
     double* pin = static_cast<double*>(h->pin);
@@ -1018,8 +1026,13 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     std::memcpy(pin + (size_t)n * d, y, sizeof(double) * n);
     std::memcpy(pin + (size_t)n * d + n, row.data(), sizeof(double) * P);
     Carver c(h->stage);
+    // With R.Inv the kernel stores its results STRAIGHT into the pinned host buffer (device-visible like any hipHostMalloc
+    // memory): no device-to-host copy of the n x n inverse behind the kernel -- 84 -> 72 us per call at n = 64, 125 -> 115 at
+    // n = 90.  (Value only: three doubles, no difference; reading the INPUTS through PCIe from the kernel is slower.)
+    const bool zo = out_Rinv != nullptr;
+    double* pout = pin + in_d;
     double* din = c.take<double>(in_d);
-    double* dout = c.take<double>(out_d);
+    double* dout = zo ? pout : c.take<double>(out_d);
     double* dX = din;
     double* dy = din + (size_t)n * d;
     double* dp = dy + n;
@@ -1035,8 +1048,7 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
         launch_small_reg_loglik(h->stream, dX, n, d, dy, dv, 1, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, dout, dout + 1, dst);
     }
     CCGP_LAUNCH_CHECK();
-    double* pout = pin + in_d;
-    CCGP_HIP(hipMemcpyAsync(pout, dout, sizeof(double) * out_d, hipMemcpyDeviceToHost, h->stream));
+    if (!zo) CCGP_HIP(hipMemcpyAsync(pout, dout, sizeof(double) * out_d, hipMemcpyDeviceToHost, h->stream));
     CCGP_HIP(hipStreamSynchronize(h->stream));
     ll = pout[0];
     beta = pout[1];

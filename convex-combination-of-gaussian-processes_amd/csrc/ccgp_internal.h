@@ -71,6 +71,10 @@ struct ccgp_handle {
   int opt_small_grid16 = 0;             // CCGP_OPT_SMALL_GRID16
   int opt_fused_cov = 0;                // CCGP_OPT_FUSED_COV
   std::vector<int> tlist_host;          // cov_kernel's tile list of the sweep in flight (host image of BlockedWs::tlist)
+  std::vector<long long> tlist_key;     // shapes and options the list in tlist_dev was built for
+  int* tlist_dev = nullptr;             // device copy of the list (CCGP_OPT_FUSED_COV only), tlist_cap pairs
+  size_t tlist_cap = 0;
+  int plan_gen_columns = 0, plan_cov_tiles = 0;   // ccgp_last_sweep_plan
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
   int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
@@ -167,7 +171,6 @@ struct BlockedWs {
   double* fin;      // nb x 2: s11 = 1'R^-1 1 and beta per matrix (prediction pass)
   double* xpad;     // npad x kMaxD: the design zero-padded to npad rows (scalar-load source of cov_kernel's columns)
   double* upad;     // nb x kMaxK x npad: u[z][c][i] = sum_k theta_ck x_ik^2 (round 4: shared by cov_kernel and the update)
-  int* tlist;       // (npad / 64)^2 + 2 ints: the 64 x 64 tiles cov_kernel has to write (pairs row tile, column tile)
   size_t a_stride;  // elements between consecutive matrices
   int ld;           // npad + 128 * (1 + ne)
   int ne;           // extra full tile rows (ceil(m / 128) for prediction, else 0)

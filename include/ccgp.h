@@ -293,6 +293,10 @@ enum {
 /* on = 0: off; 1: every id; otherwise a mask with bit (1 + id) set for each id to time */
 int ccgp_enable_timing(ccgp_handle* h, int on);
 int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches);
+/* What the LAST blocked sweep (n > 128) of this handle planned -- a diagnostic beside the timers: the number of block columns
+ * whose trailing update generated its covariance tiles (0 unless CCGP_OPT_FUSED_COV) and the number of 64 x 64 tiles per matrix
+ * left to the covariance kernel (all n_pad/64 (n_pad/64 + 1) / 2 lower tiles when nothing is generated). */
+int ccgp_last_sweep_plan(ccgp_handle* h, int* out_generating_columns, int* out_cov_tiles);
 
 #ifdef __cplusplus
 }

@@ -1,39 +1,25 @@
-import sys, time, math
-sys.path.insert(0, '.')
+"""us per sequential ccgp_logpost call (Metro's caller, HX:505-512), Qian n = 64 and Ground-Vibrations n = 90, with and without R.Inv.
+usage: python scripts/logpost_latency.py"""
+import sys, time, os, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import ccgp_amd
+import torch  # noqa: F401
+import bench
 from ccgp_amd import api
-from ccgp_amd.tables import read_table
-_, tr = read_table('tests/golden/data/qian_train.txt')
-X, y = tr[:, :4], tr[:, 4]
-s2 = float(np.var(y, ddof=1))
+
 h = api.Handle(0)
-theta_t = np.array([math.log(0.3), math.log(15.0), math.log(4.0)])
-pars = np.array([7.0, 3.0, 3.0, 28.0])
-for want in (True, False):
-    h.logpost(X, y, s2, 0, theta_t, pars, want_Rinv=want)
-    h.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(100):
-        h.logpost(X, y, s2, 0, theta_t, pars, want_Rinv=want)
-    el = (time.perf_counter() - t0) / 100
-    tm = h.get_timing()
-    h.enable_timing(False)
-    print('Rinv' if want else 'value', 'us/call %.1f' % (1e6 * el), {k: (round(1e3 * v[0] / max(v[1], 1), 1), v[1]) for k, v in tm.items() if v[1]})
-# larger n
-for n in (100, 300):
-    rng = np.random.default_rng(0)
-    Xn = rng.random((n, 3)); yn = np.sin(Xn).sum(axis=1)
+X2, y2, P2, K2, s22 = bench.cfg2_inputs()
+sets, _ = bench.cfg5_inputs()
+gvX, gvy, _ = sets[-1]
+for name, X, y, prior in (("Qian n=64", X2, y2, api.PRIOR_INVGAMMA), ("GV n=%d" % gvX.shape[0], gvX, gvy, api.PRIOR_GV)):
+    pp = [2.0, 1.0, 2.0, 30.0] if prior == api.PRIOR_INVGAMMA else None
     for want in (True, False):
-        h.logpost(Xn, yn, 1.0, 2, theta_t, None, want_Rinv=want)
+        t = [math.log(0.5), math.log(20.0), 0.6]
+        ref = h.logpost(X, y, 10.0, prior, t, pp, want)
+        for _ in range(50):
+            h.logpost(X, y, 10.0, prior, t, pp, want)
         t0 = time.perf_counter()
-        for _ in range(20):
-            h.logpost(Xn, yn, 1.0, 2, theta_t, None, want_Rinv=want)
-        print(n, 'Rinv' if want else 'value', 'us/call %.1f' % (1e6 * (time.perf_counter() - t0) / 20))
-# a speculative Metropolis batch: 7 candidates per ccgp_loglik_batch call (host pointers)
-P7 = np.array([np.concatenate([[0.8, 0.2], np.full(4, 0.3 + 0.01 * i), np.full(4, 15.0)]) for i in range(7)])
-h.loglik_batch(X, y, 2, P7, s2)
-t0 = time.perf_counter()
-for _ in range(200):
-    h.loglik_batch(X, y, 2, P7, s2)
-print('loglik_batch, 7 draws per call: us/call %.1f' % (1e6 * (time.perf_counter() - t0) / 200))
+        for i in range(400):
+            r = h.logpost(X, y, 10.0, prior, t, pp, want)
+        us = (time.perf_counter() - t0) / 400 * 1e6
+        print("%-12s R.Inv %-5s %7.1f us per call   val %.12g  sum(R.Inv) %s" % (name, want, us, r["val"], None if not want else "%.12g" % r["R_inv"].sum()), flush=True)

@@ -519,14 +519,17 @@ def test_update_loops_with_buffer_offsets_and_with_pointers_give_the_same_bits(h
     assert got[0][0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.3)[0], rel=1e-9)
 
 
-@pytest.mark.parametrize("n,d,K,B", [(300, 4, 2, 9), (1100, 5, 3, 8), (1024, 5, 3, 16), (1537, 2, 4, 3)])
-def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits(handle, n, d, K, B):
+@pytest.mark.parametrize("n,d,K,B,tail", [(300, 4, 2, 9, 0), (1100, 5, 3, 8, 0), (1024, 5, 3, 16, 0), (1537, 2, 4, 3, 0),
+                                         (640, 5, 3, 256, 1), (1000, 3, 2, 130, 1)])
+def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits(handle, n, d, K, B, tail):
     """OPT_FUSED_COV (round 4): a whole tile of the trailing update generates its covariance tile in the epilogue of the
     workgroup that consumes it (blocked.hip: update_tile_il_gen, chol_update_gen_kernel) and cov_kernel writes only the tiles
     of a host-built list (column 0, diagonal tiles, ragged edge rows, columns whose launch has tail strips).  Both evaluate
     every entry through cov_mix_term on the same u = sum theta x^2 table, so the default data flow (cov_kernel writes
     everything, the update reads it) must give the same bits: log-likelihood in both mean modes (a failing draw included), prediction (extra tile
-    rows) and gradient (identity rows); n a multiple of 128 and ragged, draw counts with and without a ragged group."""
+    rows) and gradient (identity rows); n a multiple of 128 and ragged, draw counts with and without a ragged group.
+    A block column generates only if its launch has no tail strips: the small batches run with OPT_TAIL_STRIPS off (every
+    tile whole), the large ones as they come (256 matrices: whole steps; 130: a mixture) -- and the plan is asserted."""
     from ccgp_amd import api
     X, y = synthetic_design(n, d, seed=5 * n)
     rng = np.random.default_rng(n + B)
@@ -545,12 +548,18 @@ def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits
         out += list(handle.predict_batch(X, y, K, P[:2], Xt, 1.3))
         out += list(handle.loglik_grad_batch(X, y, K, P[:2], 1.3))
         return out
-    want = run()
-    handle.set_option(api.OPT_FUSED_COV, 1)
+    handle.set_option(api.OPT_TAIL_STRIPS, tail)
     try:
+        want = run()
+        handle.set_option(api.OPT_FUSED_COV, 1)
         got = run()
+        handle.loglik_batch(X, y, K, P, 1.3)
+        generating, cov_tiles = handle.last_sweep_plan()
     finally:
         handle.set_option(api.OPT_FUSED_COV, 0)
+        handle.set_option(api.OPT_TAIL_STRIPS, 1)
+    nt64 = (n + 127) // 128 * 2
+    assert generating >= 1 and (cov_tiles < nt64 * (nt64 + 1) // 2 or n // 128 < 3), (generating, cov_tiles)   # n = 300: no whole tile below block column 1
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, b)
     assert got[2][B - 1] != 0 and not got[2][:B - 1].any() and np.isfinite(got[0][:B - 1]).all()
@@ -559,35 +568,32 @@ def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits
 
 
 def test_fused_generation_leaves_cov_kernel_only_the_listed_tiles(handle):
-    """The point of the fusion: at n = 2048 (16 tile rows) cov_kernel still writes block column 0 and the diagonal tiles,
-    about a quarter of the lower triangle.  Its share of the device time must drop accordingly -- a check that the option
-    really switches the generating kernel in (a plan that silently fused nothing would still pass the bitwise test above)."""
+    """What the option switches, read back from the sweep's plan (ccgp_last_sweep_plan): at n = 1024 (8 tile rows of 128 = 16
+    of 64: 136 lower 64 x 64 tiles per matrix) and 256 matrices (every launch a whole number of steps: no tail strips) each
+    block column from 1 on generates -- cov_kernel keeps block column 0 (31 tiles) and the other diagonal tiles (7 x 3) --; at a
+    ragged n the last tile row stays with cov_kernel too (24 more); with the option off nothing generates and every tile is
+    cov_kernel's.  (A plan that silently fused nothing would still pass the bitwise test above.)"""
     from ccgp_amd import api
-    n, d, K, B = 2048, 5, 3, 64                         # enough work per launch for the kernels, not the events, to be timed
-    X, y = synthetic_design(n, d, seed=11)
+    d, K, B = 5, 3, 256
     rng = np.random.default_rng(11)
     P = np.empty((B, K + K * d))
     for b in range(B):
         th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
         th[-1] = np.maximum(th[-1], 20.0)
         P[b] = np.concatenate([rng.dirichlet(np.ones(K)), th.ravel()])
-    def cov_ms(on):
-        handle.set_option(api.OPT_FUSED_COV, on)
-        handle.loglik_batch(X, y, K, P, 1.0)          # warm-up (workspace, clocks)
-        handle.enable_timing(True)
+    for n, want_cols, want_tiles in ((1024, 7, 31 + 21), (1000, 7, 31 + 21 + 24)):
+        X, y = synthetic_design(n, d, seed=11)
+        a = handle.loglik_batch(X, y, K, P, 1.0)
+        assert handle.last_sweep_plan() == (0, 136)
+        handle.set_option(api.OPT_FUSED_COV, 1)
         try:
-            for _ in range(3):
-                ll, _, st = handle.loglik_batch(X, y, K, P, 1.0)
-            best = handle.get_timing()["cov"][0]      # accumulated over the three evaluations
+            b = handle.loglik_batch(X, y, K, P, 1.0)
+            plan = handle.last_sweep_plan()
         finally:
-            handle.enable_timing(False)
             handle.set_option(api.OPT_FUSED_COV, 0)
-        assert not st.any()
-        return best, ll
-    fused, a = cov_ms(1)
-    plain, b = cov_ms(0)
-    np.testing.assert_array_equal(a, b)
-    assert fused < 0.7 * plain, (fused, plain)
+        np.testing.assert_array_equal(a[0], b[0])
+        assert not a[2].any() and not b[2].any()
+        assert plan == (want_cols, want_tiles), (n, plan)
 
 
 def test_small_and_blocked_agree_across_the_cutover(handle):

@@ -70,7 +70,7 @@ struct ccgp_handle {
   int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
   int opt_small_grid16 = 0;             // CCGP_OPT_SMALL_GRID16
   int opt_fused_cov = 0;                // CCGP_OPT_FUSED_COV
-  std::vector<int> tlist_host;          // cov_kernel's tile list of the sweep in flight (host image of BlockedWs::tlist)
+  std::vector<int> tlist_host;          // cov_kernel's tile list as the last plan built it (host image of tlist_dev)
   std::vector<long long> tlist_key;     // shapes and options the list in tlist_dev was built for
   int* tlist_dev = nullptr;             // device copy of the list (CCGP_OPT_FUSED_COV only), tlist_cap pairs
   size_t tlist_cap = 0;

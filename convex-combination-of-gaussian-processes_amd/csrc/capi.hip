@@ -301,66 +301,89 @@ int count_bad(const int* status, int B) {
 }
 
 // ---- tiny kernels for the literal R.Inv-based helpers (a6, a7, a10, a11) -----------------
-__global__ void rinv_terms_kernel(const double* Rinv, const double* y, int n, double beta,
-                                  double* mean_factor, double* colsum, double* scal) {
-  // one workgroup; scal[0] = 1'Rinv y, scal[1] = sum(Rinv), scal[2] = (y-b)'Rinv(y-b)
-  __shared__ double red[3][4];
-  const int tid = threadIdx.x;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int j = tid; j < n; j += blockDim.x) {
-    // column j: colSums (apply(R.Inv, 2, sum)); also 1'Rinv y = sum_j colsum_j y_j
-    double cs = 0.0;
-    for (int i = 0; i < n; ++i) cs += Rinv[i + (size_t)j * n];
-    if (colsum) colsum[j] = cs;
-    a0 += cs * y[j];
-    a1 += cs;
-  }
-  for (int i = tid; i < n; i += blockDim.x) {
-    double mf = 0.0;
-    for (int j = 0; j < n; ++j) mf = fma(Rinv[i + (size_t)j * n], y[j] - beta, mf);
-    if (mean_factor) mean_factor[i] = mf;
-    a2 += (y[i] - beta) * mf;
-  }
-  double v[3] = {a0, a1, a2};
-  for (int q = 0; q < 3; ++q) {
-    double x = v[q];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    if ((tid & 63) == 0) red[q][tid >> 6] = x;
-  }
+// (Rounds 1 - 3 let one thread walk a whole row or column of R.Inv alone: ~20 us per kernel for 4096 multiply-adds at
+// n = 64, a third of a literal call.  Now lane = row -- a column of R.Inv is contiguous --, the four waves share the columns
+// and combine in LDS in fixed order.)
+__device__ inline double wg4_sum(double x, double (&red)[4], int tid) {
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
   __syncthreads();
-  if (tid == 0)
-    for (int q = 0; q < 3; ++q) scal[q] = red[q][0] + red[q][1] + red[q][2] + red[q][3];
+  if ((tid & 63) == 0) red[tid >> 6] = x;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void predict_factors_kernel(const double* r, int m, int n, double beta,
-                                       const double* mean_factor, const double* v1, double v2,
-                                       const double* Rinv, double sigma2, double* mean, double* var) {
+__global__ __launch_bounds__(256) void rinv_terms_kernel(const double* Rinv, const double* y, int n, double beta,
+                                                         double* mean_factor, double* colsum, double* scal) {
+  // one workgroup; scal[0] = 1'Rinv y, scal[1] = sum(Rinv), scal[2] = (y-b)'Rinv(y-b)
+  __shared__ double part[2][4][64];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    // rows i0 .. i0 + 63: row sums (= column sums: R.Inv is symmetric, apply(R.Inv, 2, sum)) and (R.Inv (y - beta))_i
+    const int i = i0 + lane;
+    double cs = 0.0, mf = 0.0;
+    if (i < n) {
+#pragma unroll 4
+      for (int j = wave; j < n; j += 4) {
+        const double v = Rinv[i + (size_t)j * n];
+        cs += v;
+        mf = fma(v, y[j] - beta, mf);
+      }
+    }
+    part[0][wave][lane] = cs;
+    part[1][wave][lane] = mf;
+    __syncthreads();
+    if (wave == 0 && i < n) {
+      cs = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+      mf = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+      if (colsum) colsum[i] = cs;
+      if (mean_factor) mean_factor[i] = mf;
+      a0 += cs * y[i];
+      a1 += cs;
+      a2 += (y[i] - beta) * mf;
+    }
+    __syncthreads();
+  }
+  a0 = wg4_sum(a0, red, tid);
+  a1 = wg4_sum(a1, red, tid);
+  a2 = wg4_sum(a2, red, tid);
+  if (tid == 0) { scal[0] = a0; scal[1] = a1; scal[2] = a2; }
+}
+
+__global__ __launch_bounds__(256) void predict_factors_kernel(const double* r, int m, int n, double beta,
+                                                              const double* mean_factor, const double* v1, double v2,
+                                                              const double* Rinv, double sigma2, double* mean, double* var) {
   // one workgroup per test point t; r is m x n column-major (r[t + i*m])
-  __shared__ double red[3][4];
-  const int t = blockIdx.x, tid = threadIdx.x;
+  __shared__ double part[4][64];
+  __shared__ double red[4];
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double q = 0.0, s1 = 0.0, sm = 0.0;
-  for (int i = tid; i < n; i += blockDim.x) {
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
     double acc = 0.0;
-    for (int j = 0; j < n; ++j) acc = fma(Rinv[i + (size_t)j * n], r[t + (size_t)j * m], acc);
-    const double ri = r[t + (size_t)i * m];
-    q = fma(ri, acc, q);
-    s1 = fma(v1[i], ri, s1);
-    sm = fma(mean_factor[i], ri, sm);
+    if (i < n) {
+#pragma unroll 4
+      for (int j = wave; j < n; j += 4) acc = fma(Rinv[i + (size_t)j * n], r[t + (size_t)j * m], acc);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && i < n) {
+      acc = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+      const double ri = r[t + (size_t)i * m];
+      q = fma(ri, acc, q);
+      s1 = fma(v1[i], ri, s1);
+      sm = fma(mean_factor[i], ri, sm);
+    }
+    __syncthreads();
   }
-  double v[3] = {q, s1, sm};
-  for (int k = 0; k < 3; ++k) {
-    double x = v[k];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    if ((tid & 63) == 0) red[k][tid >> 6] = x;
-  }
-  __syncthreads();
+  q = wg4_sum(q, red, tid);
+  s1 = wg4_sum(s1, red, tid);
+  sm = wg4_sum(sm, red, tid);
   if (tid == 0) {
-    double Q = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    double S1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    double SM = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-    double u = 1.0 - S1;
-    var[t] = sigma2 * (1.0 - Q + u * u / v2);
-    mean[t] = beta + SM;
+    const double u = 1.0 - s1;
+    var[t] = sigma2 * (1.0 - q + u * u / v2);
+    mean[t] = beta + sm;
   }
 }
 

@@ -412,3 +412,39 @@ def test_ccgp_devices_routes_the_batched_calls_through_ccgp_multi(R, handle):
         R.unload()
         os.environ.pop("CCGP_DEVICES", None)
         R.L.rmock_load()
+
+
+@pytest.mark.parametrize("n,d,S,m,seed", [(9, 1, 3, 1, 1), (64, 4, 5, 33, 2), (100, 2, 2, 150, 3), (129, 3, 4, 7, 4),
+                                           (300, 5, 3, 131, 5), (520, 2, 2, 64, 6)])
+def test_batched_routines_at_random_shapes_including_the_blocked_path(R, handle, n, d, S, m, seed):
+    """The shim's batched routines hand R's column-major buffers straight through; nothing in them depends on the size of the
+    design, so they must serve n > 128 (the blocked sweep behind the same C entry points) as they serve the scripts' own
+    sizes: likelihood batch, prediction tables from a parameter matrix and from a slim frame, logpost with R.Inv, design
+    log-determinants -- each equal to api.Handle (ctypes -> the same C ABI) bit for bit."""
+    rng = np.random.default_rng(seed)
+    X, y = synthetic_design(n, d, seed)
+    s = n ** (2.0 / d) / d
+    draws = np.column_stack([rng.uniform(0.55, 0.9, S), rng.uniform(0.05, 0.3, S) * s, rng.uniform(2.0, 4.0, S) * s])
+    P = np.array([iso_row(r[0], r[1], r[2], d) for r in draws])
+    Xt = rng.random((m, d))
+    got = R.dot_call("ccgp_R_loglik_batch", R.real(X), R.real(y), R.integer(2), R.real(P), R.real(1.4), R.integer(0), R.real(0.0))
+    ll, beta, st = handle.loglik_batch(X, y, 2, P, 1.4)
+    assert not st.any() and np.array_equal(got[0], ll) and np.array_equal(got[1], beta)
+    got = R.dot_call("ccgp_R_predict_batch", R.real(X), R.real(y), R.integer(2), R.real(P), R.real(Xt), R.real(1.4))
+    mean, var, beta2, _ = handle.predict_batch(X, y, 2, P, Xt, 1.4)
+    assert got[0].shape == (S, m) and np.array_equal(got[0], mean) and np.array_equal(got[1], var) and np.array_equal(got[2], beta2)
+    slim = np.column_stack([draws, beta2])
+    got = R.dot_call("ccgp_R_prediction_table", R.frame(slim, names=["p", "theta1", "theta2", "beta"]), R.real(X), R.real(Xt),
+                     R.real(1.4), R.real(y), R.integer(0), R.real(0.0))
+    assert np.array_equal(got[0], mean) and np.array_equal(got[1], var)
+    t = np.array([np.log(draws[0, 1]), np.log(draws[0, 2]), np.log(draws[0, 0] / (1 - draws[0, 0]))])
+    from ccgp_amd import api
+    got = R.dot_call("ccgp_R_logpost", R.real(X), R.real(t), R.real(y), R.real(1.4), R.integer(api.PRIOR_GV), R.null(), R.integer(1))
+    want = handle.logpost(X, y, 1.4, api.PRIOR_GV, t, None, True)
+    assert got["val"][0] == want["val"] and got["beta"][0] == want["beta"] and np.array_equal(got["R.Inv"], want["R_inv"])
+    designs = np.stack([synthetic_design(n, d, seed + 10 + i)[0] for i in range(3)])
+    Xs = np.stack([np.asfortranarray(Dd).ravel(order="F") for Dd in designs], axis=1)
+    got = R.dot_call("ccgp_R_mixed_logdet_designs", R.real(Xs), R.integer(n), R.integer(d), R.integer(2), R.real(P[0]))
+    want_ld, _ = handle.mixed_logdet_designs(designs, 2, P[0])
+    assert np.array_equal(got, want_ld)
+    assert R.warnings() == []

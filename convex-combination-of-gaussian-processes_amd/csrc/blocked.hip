@@ -1211,8 +1211,11 @@ __global__ __launch_bounds__(256) void rhs_rows_kernel(RhsArgs g) {
   double v = 0.0;
   if (c < g.n) v = r == 0 ? g.y[c] : (r == 1 ? 1.0 : 0.0);
   Ab[g.npad + r + (size_t)c * ld] = v;
-  // extra tile rows start as zeros (the cross-correlation kernel then fills rows < m, columns < n)
-  for (int e = g.npad + kTile + r; e < ld; e += 16)
+  // extra tile rows start as zeros (the cross-correlation kernel then fills rows < m, columns < n).  Identity rows: row t
+  // stays zero left of column t, so the sweep, rinv_tile_kernel and alpha_kernel never touch a tile whose row block lies
+  // below its column block -- only the tiles on and above that diagonal are written (half of 134 MB per matrix at n = 4096)
+  const int e_end = g.identity ? min(ld, g.npad + kTile + (c / kTile + 1) * kTile) : ld;
+  for (int e = g.npad + kTile + r; e < e_end; e += 16)
     Ab[e + (size_t)c * ld] = (g.identity && e - (g.npad + kTile) == c) ? 1.0 : 0.0;
 }
 
@@ -1364,11 +1367,12 @@ struct AlphaArgs {
   double* alpha;        // nb x npad:  R^-1 (y - beta 1) = Z (z_y - beta z_1)
 };
 
-// A workgroup owns 64 rows (lane = row: a column of Z is read as 512 contiguous bytes per wave), its four waves take the
-// columns c = a0 + w, a0 + w + 4, ...; fixed summation order.  (Rounds 2 - 3: one thread per row walking its up to n columns
+// A workgroup owns 64 rows (lane = row: a column of Z is read as 512 contiguous bytes per wave), its 16 waves take the
+// columns c = a0 + w, a0 + w + 16, ...; fixed summation order.  (Rounds 2 - 3: one thread per row walking its up to n columns
 // alone -- 3.2 ms for 16 draws at n = 4096, half as long as forming R^-1.)
-__global__ __launch_bounds__(256) void alpha_kernel(AlphaArgs g) {
-  __shared__ double part[4][64];
+constexpr int kAlphaWaves = 16;
+__global__ __launch_bounds__(64 * kAlphaWaves) void alpha_kernel(AlphaArgs g) {
+  __shared__ double part[kAlphaWaves][64];
   const int b = blockIdx.y, a0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int a = a0 + lane;
@@ -1379,7 +1383,7 @@ __global__ __launch_bounds__(256) void alpha_kernel(AlphaArgs g) {
   double s = 0.0;
   if (a < g.n) {
 #pragma unroll 4
-    for (int c = a0 + wave; c < g.n; c += 4) {
+    for (int c = a0 + wave; c < g.n; c += kAlphaWaves) {
       const double z = Zrow[(size_t)c * g.ld];
       const double v = zrow[(size_t)c * g.ld] - beta * zrow[1 + (size_t)c * g.ld];
       if (c >= a) s = fma(z, v, s);
@@ -1387,7 +1391,11 @@ __global__ __launch_bounds__(256) void alpha_kernel(AlphaArgs g) {
   }
   part[wave][lane] = s;
   __syncthreads();
-  if (tid < 64) g.alpha[(size_t)b * g.npad + a0 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  if (tid < 64) {
+    double t = 0.0;
+    for (int w = 0; w < kAlphaWaves; ++w) t += part[w][tid];
+    g.alpha[(size_t)b * g.npad + a0 + tid] = t;
+  }
 }
 
 struct RinvArgs {
@@ -1857,7 +1865,7 @@ struct GroupRun {
       } else {
         const int P = dv.K + dv.K * d;
         AlphaArgs aa{w.A, w.a_stride, npad, w.ld, n, w.fin + nb, job->alpha};
-        hipLaunchKernelGGL(alpha_kernel, dim3(npad / 64, nb), dim3(256), 0, s, aa);
+        hipLaunchKernelGGL(alpha_kernel, dim3(npad / 64, nb), dim3(64 * kAlphaWaves), 0, s, aa);
         ra.X = X; ra.d = d; ra.K = dv.K; ra.params = dv.params; ra.ldp = dv.ldp; ra.draw0 = b0;
         ra.sigma2 = sigma2; ra.alpha = job->alpha; ra.gpart = job->gpart;
         hipLaunchKernelGGL(rinv_tile_kernel<true>, grid, block, gemm_lds_bytes<1>(), s, ra);

@@ -348,6 +348,7 @@ def parse_args():
     ap.add_argument("--strips", type=int, default=0, choices=[0, 1, 2],
                     help="pin the update kernel's column-strip count (ccgp_set_option; 0 = per-launch choice)")
     ap.add_argument("--no-tail-strips", action="store_true", help="every update tile whole (ccgp_set_option; measurements)")
+    ap.add_argument("--half-tail-strips", action="store_true", help="half-width tail strips only, as in rounds 2 - 3 (ccgp_set_option; measurements)")
     ap.add_argument("--no-fuse-diag", action="store_true", help="separate diag_kernel launches (ccgp_set_option; measurements)")
     ap.add_argument("--fused-cov", action="store_true",
                     help="whole update tiles generate their covariance tile, cov_kernel writes the rest (ccgp_set_option; measurements)")
@@ -507,6 +508,8 @@ def run_loglik_workload(c):
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.strips:
         h.set_option(api.OPT_UPDATE_STRIPS, args.strips)
+    if args.half_tail_strips:
+        h.set_option(api.OPT_TAIL_STRIPS, 2)
     if args.no_tail_strips:
         h.set_option(api.OPT_TAIL_STRIPS, 0)
     if args.no_fuse_diag:

@@ -69,7 +69,8 @@ struct GemmArgs {
   int fuse_diag;
   int tail_strips;   // host switch (CCGP_OPT_TAIL_STRIPS)
   int wide;          // host switch (CCGP_OPT_WIDE_OFFSETS): 64-bit-pointer loops everywhere
-  int n_s1;   // update, S = 1 kernel: tiles [0, n_s1) (dispatch order) run whole, the rest as two ring-pipelined strips
+  int n_s1;   // update, S = 1 kernel: tiles [0, n_s1) (dispatch order) run whole, the rest as tail_s ring-pipelined strips
+  int tail_s; // 2 (half-width) or 4 (quarter-width) strips per tail tile
   double* logdet_part;
   int* status;
   int n;
@@ -587,6 +588,96 @@ __device__ __forceinline__ void strip_accumulate_ring(double* smem, const double
 #undef CCGP_RMFMAS
 }
 
+// ---- quarter-width strip on the same ring (round 4) ------------------------------------------------------
+// 128 rows x 32 columns per workgroup in TileGeom<4>'s layout (wave w: rows 32 w .. 32 w + 31, all 32 columns: 2 x 2 sub-tiles,
+// four MFMAs per k-step), for the partial last step of an update launch whose tail is a QUARTER of a step (64 tiles on 256
+// CUs: 256 quarter strips fill the chip where 128 half strips filled half of it) or half a step (512 quarter strips, two per
+// CU).  Fragments, swizzle and per-accumulator MFMA order are gemm_accumulate<4, false>'s: same bits.  The Q image of a stage
+// is 8 k-rows of 256 bytes: two wave-instructions; waves 2 and 3 request the same rows again (same bytes to the same place)
+// so that every wave counts three requests per stage and the counted waits stay wave-uniform.
+__device__ __forceinline__ void strip_accumulate_ring4(double* smem, const double* P, int ldP, const double* Q,
+                                                       int ldQ, int Kdim, d4 (&acc)[2][2]) {
+  constexpr int BKd = 8, NST = 4, CW = kTile / 4;
+  constexpr int STAGE = BKd * kTile + BKd * CW;   // doubles: P image [8][128], then Q image [8][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = wave * 32;
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+  const int psrc = ((((lane >> 3) ^ (wave & 1)) << 4) + ((lane & 7) << 1));
+  const double* pP = P + psrc + (size_t)wave * ldP;
+  // Q: one wave-instruction = k-rows 4 (w & 1) + (lane >> 4), 16 lanes x 16 bytes each; parity of the row = (lane >> 4) & 1
+  const int qrk = lane >> 4, ql = lane & 15;
+  const int qsrc = ((((ql >> 3) ^ (qrk & 1)) << 4) + ((ql & 7) << 1));
+  const double* pQ = Q + qsrc + (size_t)(4 * (wave & 1) + qrk) * ldQ;
+  auto issue = [&](int slot) {
+    double* Ps_ = smem + slot * STAGE + wave * kTile;
+    double* Qs_ = smem + slot * STAGE + BKd * kTile + (wave & 1) * 4 * CW;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pP,
+                                     (__attribute__((address_space(3))) void*)Ps_, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pP + (size_t)4 * ldP),
+                                     (__attribute__((address_space(3))) void*)(Ps_ + 4 * kTile), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pQ,
+                                     (__attribute__((address_space(3))) void*)Qs_, 16, 0, 0);
+    pP += (size_t)BKd * ldP;
+    pQ += (size_t)BKd * ldQ;
+  };
+  auto wait_and_meet = [&](int later_stages) {   // as in strip_accumulate_ring: three requests per wave and stage
+    if (later_stages >= 3) __builtin_amdgcn_s_waitcnt(0x0079);
+    else if (later_stages == 2) __builtin_amdgcn_s_waitcnt(0x0076);
+    else if (later_stages == 1) __builtin_amdgcn_s_waitcnt(0x0073);
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+  };
+  const int sw = l4 & 1;
+  const int offP = l4 * kTile + l15, offQ = BKd * kTile + l4 * CW + l15;
+  int rbo[2], cbo[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    rbo[t] = (((row0 >> 4) + t) ^ sw) << 4;
+    cbo[t] = (t ^ sw) << 4;
+  }
+  double pfA[2], qfA[2], pfB[2], qfB[2];
+#define CCGP_QLOADF(PF, QF, SLOT, KK)                                                            \
+  do {                                                                                          \
+    const double* St_ = smem + (SLOT) * STAGE;                                                  \
+    _Pragma("unroll") for (int y = 0; y < 2; ++y) PF[y] = St_[(KK) * 4 * kTile + offP + rbo[y]]; \
+    _Pragma("unroll") for (int x = 0; x < 2; ++x) QF[x] = St_[(KK) * 4 * CW + offQ + cbo[x]];   \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+#define CCGP_QMFMAS(PF, QF, X0, X1)                                                              \
+  do {                                                                                          \
+    _Pragma("unroll") for (int x = (X0); x < (X1); ++x)                                         \
+      _Pragma("unroll") for (int y = 0; y < 2; ++y)                                             \
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(QF[x], PF[y], acc[x][y], 0, 0, 0);   \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+  const int nk = Kdim / BKd;
+  const int pre = nk < NST ? nk : NST;
+  for (int t = 0; t < pre; ++t) issue(t);
+  __builtin_amdgcn_sched_barrier(0);
+  wait_and_meet(pre - 1);
+  CCGP_QLOADF(pfA, qfA, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int slot = kt & (NST - 1);
+    CCGP_QLOADF(pfB, qfB, slot, 1);
+    CCGP_QMFMAS(pfA, qfA, 0, 2);
+    if (kt + 1 < nk) {
+      const int last_issued = kt + NST - 1 < nk - 1 ? kt + NST - 1 : nk - 1;
+      wait_and_meet(last_issued - (kt + 1));
+      if (kt + NST < nk) issue(slot);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    CCGP_QMFMAS(pfB, qfB, 0, 1);
+    if (kt + 1 < nk) CCGP_QLOADF(pfA, qfA, (kt + 1) & (NST - 1), 0);
+    CCGP_QMFMAS(pfB, qfB, 1, 2);
+  }
+#undef CCGP_QLOADF
+#undef CCGP_QMFMAS
+}
+
 // C = C - acc (mode 0) or C = acc (mode 1) for one strip.
 template <int S, bool THIN, bool TRI = false, bool RING = false>
 __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP, const double* Q,
@@ -595,8 +686,9 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
   constexpr int NY = TileGeom<S, THIN>::NY;
   d4 acc[NX][NY];
   if constexpr (RING) {
-    static_assert(S == 2 && !THIN && !TRI, "the four-stage ring exists for half-width update strips");
-    strip_accumulate_ring(smem, P, ldP, Q, ldQ, Kdim, acc);
+    static_assert((S == 2 || S == 4) && !THIN && !TRI, "the four-stage ring exists for half- and quarter-width update strips");
+    if constexpr (S == 2) strip_accumulate_ring(smem, P, ldP, Q, ldQ, Kdim, acc);
+    else strip_accumulate_ring4(smem, P, ldP, Q, ldQ, Kdim, acc);
   } else {
     gemm_accumulate<S, THIN, TRI>(smem, P, ldP, Q, ldQ, Kdim, acc);
   }
@@ -1045,10 +1137,10 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
     const int Lt = L - nb8;
     int u1;                                             // tile index in (group, tile, matrix-in-group) order
     if (S == 1) {
-      if (Lt >= g.n_s1) {                               // tail: q = 16 a + 8 strip + m  ->  tile n_s1 + 8 a + m
+      if (Lt >= g.n_s1) {                               // tail: q = 8 tail_s a + 8 strip + m  ->  tile n_s1 + 8 a + m
         const int q = Lt - g.n_s1;
-        u1 = g.n_s1 + ((q >> 4) << 3) + (q & 7);
-        strip = (q >> 3) & 1;
+        u1 = g.n_s1 + ((q / (8 * g.tail_s)) << 3) + (q & 7);
+        strip = (q >> 3) % g.tail_s;
         ring = true;
       } else {
         u1 = Lt;
@@ -1078,7 +1170,7 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   }
   double* Ab = g.A + (size_t)b * g.a_stride;
   const bool thin = i == g.nt;
-  const int c0 = strip * (ring ? kTile / 2 : kTile / S);   // first column of this strip inside the tile
+  const int c0 = strip * (ring ? kTile / g.tail_s : kTile / S);   // first column of this strip inside the tile
 
   // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
   // zero (skipped) and the update's k-sum starts at te
@@ -1117,7 +1209,11 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
     if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
   }
   if constexpr (MODE == 0 && S == 1) {
-    if (ring) { gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
+    if (ring) {
+      if (g.tail_s == 4) gemm_tile<4, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
+      else gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
+      return;
+    }
     if (!g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
       // GEN (chol_update_gen_kernel, CCGP_OPT_FUSED_COV): tile rows of the matrix proper that lie wholly inside n generate
       // their covariance tile (the host decides per launch and keeps cov_kernel's tile list in step: GroupRun::begin).
@@ -1160,13 +1256,20 @@ CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2, false)
 // takes ceil(W1 / 256) steps (one workgroup per CU saturates its MFMA pipes).  If the last step holds `rem` <= 128
 // TILES (the diagonal workgroups are dispatched first and are never in it unless the whole launch is one step),
 // running those tiles as 2 rem ring-pipelined half-width strips on otherwise idle CUs cuts that step to about half.
-static int update_tail(int nb8, int tiles) {
+// Round 4: quarter-width strips where they fill the step -- four per tail tile if that leaves at most two workgroups per CU
+// in the last step (a quarter step of tiles: 256 strips on 256 CUs; half a step: 512, two per CU); `quarters` = 0 keeps the
+// round-3 policy (CCGP_OPT_TAIL_STRIPS = 2).
+static int update_tail(int nb8, int tiles, int quarters, int* ts) {
   const long w1 = (long)nb8 * (1 + tiles), all_tiles = (long)nb8 * tiles;
   const long rem = w1 % 256;
+  *ts = 2;
   if (rem == 0 || all_tiles == 0) return 0;
   long tail = rem < all_tiles ? rem : all_tiles;
-  if (rem + tail > 256) return 0;                    // the strips would not fit the same step
   if (tail != rem && w1 > 256) return 0;             // whole tiles left in the last step: nothing gained
+  // (only behind at least one full step: a launch that is a single partial step is bound by its diagonal workgroups, and
+  // quarter strips there cost 0.13 ms at block column 30 of the 64-matrix slice, 3 % of a 16-matrix batch)
+  if (quarters && w1 > 256 && (rem - tail) + 4 * tail <= 512) { *ts = 4; return (int)tail; }
+  if (rem + tail > 256) return 0;                    // the strips would not fit the same step
   return (int)tail;                                  // a multiple of 8 (nb8 is)
 }
 
@@ -1175,9 +1278,11 @@ static void launch_gemm(hipStream_t s, GemmArgs g, int mode, int S) {
   int units = nb8 * gemm_units_per_matrix(mode, g.nt, g.j, g.ne, S, g.rows_only);
   if (mode == 0 && !g.rows_only) {
     const int tiles = (g.nt - 1 - g.j) + g.ne;
-    const int tail = (S == 1 && g.tail_strips) ? update_tail(nb8, tiles) : 0;
+    int ts = 2;
+    const int tail = (S == 1 && g.tail_strips) ? update_tail(nb8, tiles, g.tail_strips == 1, &ts) : 0;
     g.n_s1 = nb8 * tiles - tail;
-    units = nb8 + (S == 1 ? g.n_s1 + 2 * tail : nb8 * tiles * S);
+    g.tail_s = ts;
+    units = nb8 + (S == 1 ? g.n_s1 + ts * tail : nb8 * tiles * S);
   }
   const dim3 grid(units), block(256);
   if (mode == 0) {
@@ -1739,7 +1844,8 @@ struct GroupRun {
                     (size_t)npad * (size_t)w.ld * 8 < 0xFFFF0000ull;
     for (int j = 1; j < nt && ok; ++j) {
       const int tiles = (nt - 1 - j) + w.ne;
-      const bool whole = !h->opt_tail_strips || update_tail(nb8, tiles) == 0;
+      int ts_ = 2;
+      const bool whole = !h->opt_tail_strips || update_tail(nb8, tiles, h->opt_tail_strips == 1, &ts_) == 0;
       fused[j] = whole && ((size_t)j * kTile + 32) * (size_t)w.ld * 8 < 0xFFFF0000ull;   // fits_buffer_offsets(j * 128, ld)
     }
     any_fused = false;

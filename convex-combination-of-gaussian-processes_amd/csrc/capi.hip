@@ -561,7 +561,7 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
     h->opt_small_lds = value;
     return CCGP_OK;
   }
-  if (option == CCGP_OPT_TAIL_STRIPS && (value == 0 || value == 1)) {
+  if (option == CCGP_OPT_TAIL_STRIPS && value >= 0 && value <= 2) {
     h->opt_tail_strips = value;
     return CCGP_OK;
   }

@@ -100,7 +100,8 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *   CCGP_OPT_FUSE_DIAG      1 (default) = the update launch's diagonal-tile workgroup also factorises and inverts
  *                           the diagonal block; 0 = a separate diag_kernel launch per block column
  *   CCGP_OPT_TAIL_STRIPS    1 (default) = the tiles of an update launch's last, partial step of 256 workgroups run
- *                           as two half-width strips each; 0 = every tile whole
+ *                           as four quarter-width or two half-width strips each, whichever fills the step; 2 = half-width
+ *                           strips only (rounds 2 - 3); 0 = every tile whole (same bits all three)
  *   CCGP_OPT_WIDE_OFFSETS   0 (default) = the update loops address their panels through 32-bit buffer offsets wherever a
  *                           panel spans less than 4 GiB; 1 = always the 64-bit-pointer loops that larger matrices
  *                           fall back to (same bits: the tests hold one against the other)

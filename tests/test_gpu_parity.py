@@ -596,6 +596,41 @@ def test_fused_generation_leaves_cov_kernel_only_the_listed_tiles(handle):
         assert plan == (want_cols, want_tiles), (n, plan)
 
 
+@pytest.mark.parametrize("n,B", [(1100, 64), (1100, 16), (700, 9), (1537, 40)])
+def test_tail_tiles_whole_as_half_strips_and_as_quarter_strips_give_the_same_bits(handle, n, B):
+    """The tiles of an update launch's last, partial step of 256 workgroups run whole (OPT_TAIL_STRIPS 0), as two half-width
+    ring strips (2: rounds 2 - 3) or as four quarter-width ones where that fills the step (1: default since round 4).  With 64
+    matrices at n = 1100 the launches of block columns 2, 3, 4 and 7 end in three quarters, a half, a quarter of a step
+    and a single partial step: every policy is exercised.  Each output element sums its k four at a time in ascending order
+    in all three forms: likelihood, prediction (extra tile rows) and gradient (identity rows) bit for bit."""
+    from ccgp_amd import api
+    d, K = 3, 2
+    X, y = synthetic_design(n, d, seed=3 * n + B)
+    rng = np.random.default_rng(n + B)
+    P = np.empty((B, K + K * d))
+    for b in range(B):
+        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
+        th[-1] = np.maximum(th[-1], 2.0 * n ** (2.0 / d) / d)
+        P[b] = np.concatenate([rng.dirichlet(np.ones(K)), th.ravel()])
+    Xt = rng.random((70, d))
+    def run(mode):
+        handle.set_option(api.OPT_TAIL_STRIPS, mode)
+        try:
+            ll, beta, st = handle.loglik_batch(X, y, K, P, 1.3)
+            mean, var, _, st2 = handle.predict_batch(X, y, K, P[:5], Xt, 1.3)
+            _, _, grad, st3 = handle.loglik_grad_batch(X, y, K, P[:3], 1.3)
+        finally:
+            handle.set_option(api.OPT_TAIL_STRIPS, 1)
+        assert not st.any() and not st2.any() and not st3.any()
+        return ll, beta, mean, var, grad
+    whole, quarters, halves = run(0), run(1), run(2)
+    for a, b, c in zip(whole, quarters, halves):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
+    w, Th = orc.unpack_params(P[0], K, d)
+    assert whole[0][0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.3)[0], rel=1e-8)
+
+
 def test_small_and_blocked_agree_across_the_cutover(handle):
     """n = 128 runs the fused kernel, n = 129 the blocked one: appending one far-away,
     nearly independent point must change the likelihood by exactly its own marginal term."""

@@ -520,7 +520,7 @@ def test_update_loops_with_buffer_offsets_and_with_pointers_give_the_same_bits(h
 
 
 @pytest.mark.parametrize("n,d,K,B,tail", [(300, 4, 2, 9, 0), (1100, 5, 3, 8, 0), (1024, 5, 3, 16, 0), (1537, 2, 4, 3, 0),
-                                         (640, 5, 3, 256, 1), (1000, 3, 2, 130, 1)])
+                                         (640, 5, 3, 256, 1), (1000, 3, 2, 128, 1)])
 def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits(handle, n, d, K, B, tail):
     """OPT_FUSED_COV (round 4): a whole tile of the trailing update generates its covariance tile in the epilogue of the
     workgroup that consumes it (blocked.hip: update_tile_il_gen, chol_update_gen_kernel) and cov_kernel writes only the tiles
@@ -529,7 +529,7 @@ def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits
     everything, the update reads it) must give the same bits: log-likelihood in both mean modes (a failing draw included), prediction (extra tile
     rows) and gradient (identity rows); n a multiple of 128 and ragged, draw counts with and without a ragged group.
     A block column generates only if its launch has no tail strips: the small batches run with OPT_TAIL_STRIPS off (every
-    tile whole), the large ones as they come (256 matrices: whole steps; 130: a mixture) -- and the plan is asserted."""
+    tile whole), the large ones as they come (256 matrices: whole steps; 128: every other block column) -- and the plan is asserted."""
     from ccgp_amd import api
     X, y = synthetic_design(n, d, seed=5 * n)
     rng = np.random.default_rng(n + B)

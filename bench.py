@@ -352,6 +352,11 @@ def parse_args():
     ap.add_argument("--no-fuse-diag", action="store_true", help="separate diag_kernel launches (ccgp_set_option; measurements)")
     ap.add_argument("--fused-cov", action="store_true",
                     help="whole update tiles generate their covariance tile, cov_kernel writes the rest (ccgp_set_option; measurements)")
+    ap.add_argument("--sched", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="blocked sweep: 1 = dataflow tile scheduler, two workgroups per CU (library default); 2 = one per CU; "
+                         "0 = one launch per phase and block column (rounds 1 - 4) (ccgp_set_option; measurements)")
+    ap.add_argument("--sched-policy", type=int, default=-1, choices=[-1, 0, 1],
+                    help="scheduler: 1 = a CU's second workgroup only takes tiles while a backlog exists (default); 0 = always")
     ap.add_argument("--small-grid16", action="store_true",
                     help="64 < n <= 104 on the 16 x 16 thread grid of rounds 1 - 3 instead of one wave per matrix (ccgp_set_option; measurements)")
     ap.add_argument("--ws-limit-gib", type=float, default=0.0,
@@ -518,6 +523,10 @@ def run_loglik_workload(c):
         h.set_option(api.OPT_SMALL_GRID16, 1)
     if args.fused_cov:
         h.set_option(api.OPT_FUSED_COV, 1)
+    if args.sched >= 0:
+        h.set_option(api.OPT_SCHED, args.sched)
+    if args.sched_policy >= 0:
+        h.set_option(api.OPT_SCHED_POLICY, args.sched_policy)
     if args.ws_limit_gib > 0:
         h.set_workspace_limit(int(args.ws_limit_gib * 2 ** 30))
     h.reserve(n, d, K, max(B, 1), 0)
@@ -541,7 +550,7 @@ def run_loglik_workload(c):
     # per launch are not free: 96 launch groups per step); the per-kernel breakdown comes from one extra,
     # untimed step afterwards, and a second region of the same K steps WITHOUT any event gives the cost of the
     # in-region events (notiming_ms_per_step).
-    main_id = "update" if n > 128 else "fused"
+    main_id = "fused" if n <= 128 else ("update" if (args.sched == 0 or args.fused_cov or args.strips or args.no_fuse_diag) else "sweep")
     h.enable_timing(True, only=[main_id])
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -601,7 +610,27 @@ def run_loglik_workload(c):
             "kernel_ms_per_step": {k: v[0] for k, v in breakdown.items() if v[1]},
             "kernel_ms_per_step_source": "one extra step with every launch group timed (outside the timed region)",
         }
-        if n > 128:
+        if n > 128 and main_id == "sweep":
+            # the scheduled sweep: ONE launch per chunk holds every update, diagonal and panel-solve tile, so the kernel is
+            # priced with the factorisation's whole algorithmic count n^3 / 3 per matrix ("only the n^3/3 potrf
+            # flops count") -- NOT comparable with the launch-per-phase rows of earlier rounds, whose roofline kernel was the
+            # update alone (0.95 n^3 / 3 in 0.86 of the time)
+            sw_ms, sw_launches = timing["sweep"]
+            sw_ms = sw_ms or float("nan")
+            flops = (n ** 3 / 3.0) * B * args.steps
+            ach = flops / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0
+            traffic, traffic_src = pmc_traffic("chol_sched", B) if n == 4096 else (None, None)
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
+                               "traffic_source": traffic_src,
+                               "kernel": "chol_sched_kernel (blocked Cholesky sweep of the chunk as one persistent launch: update, "
+                                         "diagonal and panel-solve tiles from dependency-driven queues, f64 MFMA)",
+                               "launches": sw_launches,
+                               "avg_launch_ms": sw_ms / max(sw_launches, 1),
+                               "flops_per_launch": flops / max(sw_launches, 1),
+                               "flops_note": "n^3/3 per matrix (whole factorisation); the update tiles alone are %.3e per matrix" % update_kernel_flops(n)}
+        elif n > 128:
             upd_ms, upd_launches = timing["update"]
             upd_ms = upd_ms or float("nan")
             flops = update_kernel_flops(n) * B * args.steps   # this rank's launches

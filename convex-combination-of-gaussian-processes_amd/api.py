@@ -19,7 +19,8 @@ PRIOR_INVGAMMA, PRIOR_GV, PRIOR_ISO, PRIOR_ANI = 0, 1, 2, 3
 T_COV, T_UPDATE, T_DIAG, T_TRSM, T_SOLVE, T_FUSED = range(6)
 KERNEL_GAUSS, KERNEL_MATERN, KERNEL_MATERN_SPLINE = 0, 1, 2
 OPT_UPDATE_STRIPS, OPT_SMALL_LDS, OPT_FUSE_DIAG, OPT_TAIL_STRIPS, OPT_WIDE_OFFSETS, OPT_SMALL_GRID16, OPT_FUSED_COV = 0, 1, 2, 3, 4, 5, 6
-TIMING_NAMES = ("cov", "update", "diag", "trsm", "solve", "fused")
+OPT_SCHED, OPT_SCHED_POLICY = 7, 8
+TIMING_NAMES = ("cov", "update", "diag", "trsm", "solve", "fused", "sweep")
 
 _dp = POINTER(c_double)
 _ip = POINTER(c_int)

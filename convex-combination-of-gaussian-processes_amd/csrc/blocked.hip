@@ -38,12 +38,22 @@
 #include <vector>
 
 #include "ccgp_internal.h"
+#include "sched_logic.h"
 
 namespace ccgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// threadIdx.x as the tile code sees it: behind an asm the compiler cannot look through, so that nothing derived from it is
+// hoisted out of the persistent loop of chol_sched_kernel and kept live across every tile variant (which cost 256 VGPRs and
+// 416 B of scratch per lane); each variant recomputes its few lane offsets per tile instead.
+__device__ __forceinline__ int tid_now() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
 
 
 struct GemmArgs {
@@ -137,7 +147,7 @@ __device__ __forceinline__ void gemm_accumulate(double* smem, const double* P, i
   constexpr int STAGE = BKs * kTile + BKs * CW;        // doubles per stage, unpadded
   constexpr int CPI = kTile / CW;                      // Q columns covered by one wave-instruction (1, 2, 4)
   constexpr int QI = BKs / CPI / 4;                    // Q wave-instructions per wave per stage (4, 2, 1)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
   const int row0 = TileGeom<S, THIN>::row0(wave);
   const int col0 = TileGeom<S, THIN>::col0(wave);
   const bool active = !THIN || col0 < CW;
@@ -267,7 +277,7 @@ __device__ __forceinline__ void tile_accumulate_il(double* smem, const double* P
                                                    int ldQ, int Kdim, d4 (&acc)[4][4]) {
   constexpr int BKs = 16, STAGE = 2 * BKs * kTile;     // doubles per stage: P image [16][128], then Q image [16][128]
   typedef double d2 __attribute__((ext_vector_type(2)));
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = tid_now(), lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 64;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -359,7 +369,7 @@ __device__ __forceinline__ void update_tile_il(double* smem, const double* P, in
                                                int Kdim, double* C, int ld) {
   d4 acc[4][4];
   tile_accumulate_il(smem, P, ldP, Q, ldQ, Kdim, acc);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid_now() & 63, wave = tid_now() >> 6;
   const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 64;
   const int l15 = lane & 15, l4 = lane >> 4;
   double* Cl = C + row0 + 4 * l15 + (size_t)(col0 + 4 * l4) * ld;
@@ -397,7 +407,7 @@ __device__ __forceinline__ void update_tile_il_gen(double* smem, const double* P
   d4 acc[4][4];
   tile_accumulate_il(smem, P, ldP, Q, ldQ, Kdim, acc);
   typedef double d2 __attribute__((ext_vector_type(2)));
-  const int d = g.d, K = g.K, tid = threadIdx.x;
+  const int d = g.d, K = g.K, tid = tid_now();
   double* etab = smem;
   double* xs = etab + kExpTableDoubles;      // [K][d][128]
   double* xc = xs + (size_t)K * d * kTile;   // [d][128]
@@ -503,7 +513,7 @@ __device__ __forceinline__ void strip_accumulate_ring(double* smem, const double
                                                       int ldQ, int Kdim, d4 (&acc)[2][4]) {
   constexpr int BKd = 8, NST = 4, CW = kTile / 2;
   constexpr int STAGE = BKd * kTile + BKd * CW;   // doubles: P image [8][128], then Q image [8][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
   const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 32;
   const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
@@ -599,7 +609,7 @@ __device__ __forceinline__ void strip_accumulate_ring4(double* smem, const doubl
                                                        int ldQ, int Kdim, d4 (&acc)[2][2]) {
   constexpr int BKd = 8, NST = 4, CW = kTile / 4;
   constexpr int STAGE = BKd * kTile + BKd * CW;   // doubles: P image [8][128], then Q image [8][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
   const int row0 = wave * 32;
   const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
@@ -692,7 +702,7 @@ __device__ __forceinline__ void gemm_tile(double* smem, const double* P, int ldP
   } else {
     gemm_accumulate<S, THIN, TRI>(smem, P, ldP, Q, ldQ, Kdim, acc);
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid_now() & 63, wave = tid_now() >> 6;
   const int row0 = TileGeom<S, THIN>::row0(wave), col0 = TileGeom<S, THIN>::col0(wave);
   const int l15 = lane & 15, l4 = lane >> 4;
   if (THIN && col0 >= TileGeom<S, THIN>::CW) return;
@@ -741,7 +751,7 @@ __device__ __forceinline__ void diag_rhs_accumulate(double* smem, const double* 
   constexpr int NR = W < 2 ? 5 : 4;                    // stage requests of this wave (waves 0, 1 also stage T)
   auto frag_of = [](int cb) constexpr { return cb <= CBMAX ? cb : CBMAX + 1 + (cb - 2 * W); };
   auto cb_of_frag = [](int f) constexpr { return f <= CBMAX ? f : 2 * W + (f - CBMAX - 1); };
-  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, sw = l4 & 1;
+  const int lane = tid_now() & 63, l15 = lane & 15, l4 = lane >> 4, sw = l4 & 1;
 
   const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)Tp, 0, -1, 0x00020000);
@@ -837,7 +847,7 @@ __device__ __forceinline__ void diag_rhs_tile(double* smem, const double* Qp, co
   constexpr int TR = 16;                                // right-hand-side rows staged
   [[maybe_unused]] constexpr int STAGE = BKs * kTile + BKs * TR;         // doubles per stage
   constexpr int NS = 11;                                // sub-tiles per wave: 9 of the triangle + 2 right-hand-side
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = tid_now(), lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int rA = wave, rB = 7 - wave;
@@ -1000,7 +1010,7 @@ __device__ __forceinline__ void diag_factor(const DiagArgs& g, int b, double* ld
   double (*colbuf)[256] = reinterpret_cast<double (*)[256]>(lds);
   double* dvec = lds + 2 * 256;
   double* red = dvec + kTile;
-  const int tid = threadIdx.x, ty = tid & 15, tx = tid >> 4;
+  const int tid = tid_now(), ty = tid & 15, tx = tid >> 4;
   const int ld = g.ld;
   double* C = g.A + (size_t)b * g.a_stride + (size_t)g.j * kTile + (size_t)g.j * kTile * ld;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
@@ -1109,28 +1119,101 @@ __host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, in
   return mode == 0 ? 1 + ((nt - 1 - j) + ne) * S : (nt - j) + ne;
 }
 
+// One unit of block column j for matrix b: tile row i (i == nt: trsm's thin right-hand-side row; i > nt: extra rows),
+// column strip `strip` of S (or of g.tail_s ring strips).  Shared by the launch-per-phase kernels (gemm_dispatch maps
+// blockIdx to a unit) and the dataflow scheduler (chol_sched_kernel takes units from a queue).
+template <int MODE, int S, bool GEN = false>
+__device__ __forceinline__ void gemm_unit(const GemmArgs& g, double* smem, int j, int b, int i, int strip, bool ring) {
+  const int ld = g.ld;
+  double* Ab = g.A + (size_t)b * g.a_stride;
+  const bool thin = i == g.nt;
+  const int c0 = strip * (ring ? kTile / g.tail_s : kTile / S);   // first column of this strip inside the tile
+
+  // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
+  // zero (skipped) and the update's k-sum starts at te
+  int k0 = 0;
+  if (g.extra_lower && i > g.nt) {
+    const int te = i - g.nt - 1;
+    if (j < te || (MODE == 0 && j == te)) return;
+    k0 = te * kTile;
+  }
+  // tile row i: rows i*128.. of the matrix array, or -- extra rows kept in their own buffer -- of E
+  double* rowbase = Ab + (size_t)i * kTile;
+  int rld = ld;
+  if (g.E && i > g.nt) {
+    rowbase = g.E + (size_t)b * g.e_stride + (size_t)(i - g.nt - 1) * kTile;
+    rld = g.lde;
+  }
+  const double* P;
+  const double* Q;
+  int ldP, ldQ, Kdim;
+  if (MODE == 0) {
+    P = rowbase + (size_t)k0 * rld;
+    Q = Ab + (size_t)j * kTile + c0 + (size_t)k0 * ld;
+    ldP = rld;
+    ldQ = ld;
+    Kdim = j * kTile - k0;
+  } else {
+    P = rowbase + (size_t)j * kTile * rld;
+    Q = g.invd + (size_t)b * g.invd_stride + (size_t)j * kTile * kTile + c0;
+    ldP = rld;
+    ldQ = kTile;
+    Kdim = kTile;
+  }
+  double* C = rowbase + ((size_t)j * kTile + c0) * rld;
+  constexpr bool TRI = MODE == 1 && S == 1;   // trsm: Q is the lower-triangular inverse block
+  if constexpr (MODE == 1) {
+    if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
+  }
+  if constexpr (MODE == 0 && S == 1) {
+    if (ring) {
+      if (g.tail_s == 4) gemm_tile<4, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
+      else gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
+      return;
+    }
+    if (!g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
+      // GEN (chol_update_gen_kernel, CCGP_OPT_FUSED_COV): tile rows of the matrix proper that lie wholly inside n generate
+      // their covariance tile (the host decides per launch and keeps cov_kernel's tile list in step: GroupRun::begin).
+      // A kernel of its own: the generating epilogue needs 256 VGPRs and 200 B of scratch, the plain one neither.
+      if constexpr (GEN) {
+        if (i < g.nt && (i + 1) * kTile <= g.n) {
+          update_tile_il_gen(smem, P, ldP, Q, ldQ, Kdim, C, rld, g, b, i);
+          return;
+        }
+      }
+      update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
+      return;
+    }
+  }
+  gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
+}
+
+// The diagonal workgroup of block column j >= 1 for matrix b: T_jj and the right-hand-side rows minus the finished panel,
+// then (fuse_diag) the factorisation and inverse of the block.
+__device__ __forceinline__ void diag_unit(const GemmArgs& g, double* smem, int j, int b) {
+  const int ld = g.ld;
+  double* Ab = g.A + (size_t)b * g.a_stride;
+  diag_rhs_tile(smem, Ab + (size_t)j * kTile, Ab + g.npad, ld, j * kTile,
+                Ab + (size_t)j * kTile + (size_t)j * kTile * ld, Ab + g.npad + (size_t)j * kTile * ld, g.wide);
+  if (g.fuse_diag) {
+    // T_jj went to memory through this CU's L1; the waves of the workgroup read it back in diag_factor's
+    // thread layout.  All waves of a workgroup share that L1, so workgroup scope is enough: __syncthreads is
+    // release(workgroup) + s_barrier + acquire(workgroup) -- no L2 write-back, no cache invalidate
+    __syncthreads();
+    DiagArgs dg{g.A, g.a_stride, g.npad, g.invd, g.invd_stride, g.logdet_part, g.status, j, g.nt, g.nb, g.n, g.ld, g.ptol};
+    diag_factor(dg, b, smem);   // the staging LDS is free: the K loop ended on a barrier
+  }
+}
+
 template <int MODE, int S, bool GEN = false>
 __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   const int L = blockIdx.x;
-  const int ld = g.ld;
   int b, i, strip = 0;
   bool ring = false;
   if (MODE == 0 && !g.rows_only) {
     const int nb8 = (g.nb + 7) & ~7;
     if (L < nb8) {
-      b = L;
-      if (b >= g.nb) return;
-      double* Ab = g.A + (size_t)b * g.a_stride;
-      diag_rhs_tile(smem, Ab + (size_t)g.j * kTile, Ab + g.npad, ld, g.j * kTile,
-                    Ab + (size_t)g.j * kTile + (size_t)g.j * kTile * ld, Ab + g.npad + (size_t)g.j * kTile * ld, g.wide);
-      if (g.fuse_diag) {
-        // T_jj went to memory through this CU's L1; the waves of the workgroup read it back in diag_factor's
-        // thread layout.  All waves of a workgroup share that L1, so workgroup scope is enough: __syncthreads is
-        // release(workgroup) + s_barrier + acquire(workgroup) -- no L2 write-back, no cache invalidate
-        __syncthreads();
-        DiagArgs dg{g.A, g.a_stride, g.npad, g.invd, g.invd_stride, g.logdet_part, g.status, g.j, g.nt, g.nb, g.n, g.ld, g.ptol};
-        diag_factor(dg, b, smem);   // the staging LDS is free: the K loop ended on a barrier
-      }
+      if (L < g.nb) diag_unit(g, smem, g.j, L);
       return;
     }
     const int nfull = (g.nt - 1 - g.j) + g.ne;          // tiles per matrix
@@ -1168,67 +1251,7 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
       i = g.j + 1 + u;
     }
   }
-  double* Ab = g.A + (size_t)b * g.a_stride;
-  const bool thin = i == g.nt;
-  const int c0 = strip * (ring ? kTile / g.tail_s : kTile / S);   // first column of this strip inside the tile
-
-  // identity rows: block row te of Z = L^-T starts at block column te, so tiles left of it are
-  // zero (skipped) and the update's k-sum starts at te
-  int k0 = 0;
-  if (g.extra_lower && i > g.nt) {
-    const int te = i - g.nt - 1;
-    if (g.j < te || (MODE == 0 && g.j == te)) return;
-    k0 = te * kTile;
-  }
-  // tile row i: rows i*128.. of the matrix array, or -- extra rows kept in their own buffer -- of E
-  double* rowbase = Ab + (size_t)i * kTile;
-  int rld = ld;
-  if (g.E && i > g.nt) {
-    rowbase = g.E + (size_t)b * g.e_stride + (size_t)(i - g.nt - 1) * kTile;
-    rld = g.lde;
-  }
-  const double* P;
-  const double* Q;
-  int ldP, ldQ, Kdim;
-  if (MODE == 0) {
-    P = rowbase + (size_t)k0 * rld;
-    Q = Ab + (size_t)g.j * kTile + c0 + (size_t)k0 * ld;
-    ldP = rld;
-    ldQ = ld;
-    Kdim = g.j * kTile - k0;
-  } else {
-    P = rowbase + (size_t)g.j * kTile * rld;
-    Q = g.invd + (size_t)b * g.invd_stride + (size_t)g.j * kTile * kTile + c0;
-    ldP = rld;
-    ldQ = kTile;
-    Kdim = kTile;
-  }
-  double* C = rowbase + ((size_t)g.j * kTile + c0) * rld;
-  constexpr bool TRI = MODE == 1 && S == 1;   // trsm: Q is the lower-triangular inverse block
-  if constexpr (MODE == 1) {
-    if (thin) { gemm_tile<S, true, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE); return; }
-  }
-  if constexpr (MODE == 0 && S == 1) {
-    if (ring) {
-      if (g.tail_s == 4) gemm_tile<4, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
-      else gemm_tile<2, false, false, true>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
-      return;
-    }
-    if (!g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
-      // GEN (chol_update_gen_kernel, CCGP_OPT_FUSED_COV): tile rows of the matrix proper that lie wholly inside n generate
-      // their covariance tile (the host decides per launch and keeps cov_kernel's tile list in step: GroupRun::begin).
-      // A kernel of its own: the generating epilogue needs 256 VGPRs and 200 B of scratch, the plain one neither.
-      if constexpr (GEN) {
-        if (i < g.nt && (i + 1) * kTile <= g.n) {
-          update_tile_il_gen(smem, P, ldP, Q, ldQ, Kdim, C, rld, g, b, i);
-          return;
-        }
-      }
-      update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
-      return;
-    }
-  }
-  gemm_tile<S, false, TRI>(smem, P, ldP, Q, ldQ, Kdim, C, rld, MODE);
+  gemm_unit<MODE, S, GEN>(g, smem, g.j, b, i, strip, ring);
 }
 
 // distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
@@ -1244,6 +1267,214 @@ CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2, false)
 // strips of one tile would race
 CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2, false)
 #undef CCGP_DEFINE_GEMM
+
+// ---- dataflow scheduler: the whole sweep of a chunk as ONE persistent launch --------------------------------------------
+// Round 5.  Instead of one update and one trsm launch per block column, workgroups take tiles -- D(j): diagonal workgroup,
+// U(i, j): whole update tile, T(i, j): panel-solve tile -- from per-XCD FIFO queues that finished tiles fill
+// (sched_logic.h has the dependency rules and the progress argument).  Tiles run the SAME device code in the same k order
+// as the launches (gemm_unit / diag_unit), so the bits do not change; what changes is that nothing waits for the slowest
+// workgroup of a launch: a matrix whose block column is done goes on while others are still in it, the panel solves
+// (HBM-bound when all 256 CUs run them at once) and the short-K updates of the first block columns mix with MFMA-bound
+// tiles of other matrices, and 63 launch boundaries disappear.
+//   pop    : idx = head[q]++ ; wait until slot idx of queue q is non-zero (bounded: a dependency bug sets the abort flag and
+//            every workgroup leaves -- the sweep then reports failure for the chunk instead of hanging the device)
+//   finish : every wave releases its stores at agent scope, barrier, then wave 0 applies the arrivals (one lane per row for the
+//            fan-outs of a diagonal block and of a pivot-row solve) and stores the tasks that became ready
+// Memory model: tile data crosses workgroups only through  release fence (agent) -> relaxed RMW / store  on one side and
+// relaxed load -> acquire fence (agent)  on the other; a counter's last arriver fences acq_rel between its RMW and its
+// announcement, so earlier arrivers' tiles are visible to whoever runs the announced task.
+// Placement: a workgroup serves the queue of the XCD it runs on (XCC_ID), so a matrix's tiles share the column panel in one
+// L2 as they do under the launches' blockIdx % 8 rule; when its queue is handed out it moves on to the next one, so every
+// queue is drained wherever the workgroups landed.  Two workgroups fit a CU; with `policy` bit 0 the second one of a CU only
+// takes work while a backlog exists (tail > head), so that a few ready tiles spread over the CUs instead of pairing up.
+struct SchedArgs {
+  GemmArgs g;
+  int* ctrl;                     // [q * 16 + 0] head, [+1] tail, [+2] tasks of queue q, [+3] slot offset; [128] abort, [129] longest wait (10 ns)
+  unsigned long long* slots;
+  int* counters;                 // nb x counters_per_matrix
+  int* cu_seen;                  // [8 * 128]: workgroups that registered on each CU
+  int policy;
+  unsigned timeout_10ns;         // a wait longer than this aborts the sweep
+};
+constexpr int kSchedCtrlInts = 256;
+
+__device__ __forceinline__ int sched_ld(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// thread 0: next task word of this workgroup, or 0 when every queue is handed out (or the sweep was aborted)
+__device__ inline unsigned long long sched_pop(const SchedArgs& a, int& q, int& left, int secondary) {
+  while (left > 0) {
+    int* ctl = a.ctrl + q * 16;
+    const int N = ctl[2];
+    unsigned long long t0 = 0;
+    unsigned polls = 0;
+    auto overdue = [&]() {   // every 256 polls: abort flag, and the clock (100 MHz)
+      if ((++polls & 255u) != 0) return false;
+      if (sched_ld(a.ctrl + 128)) return true;
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > (unsigned long long)a.timeout_10ns) {
+        __hip_atomic_store(a.ctrl + 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+      }
+      return false;
+    };
+    if (secondary && N > 0) {
+      for (;;) {
+        const int hd = sched_ld(ctl), tl = sched_ld(ctl + 1);
+        if (hd >= N || tl > hd) break;
+        if (overdue()) return 0;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    const int idx = N > 0 ? __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    if (idx < N) {
+      const unsigned long long* slot = a.slots + (size_t)ctl[3] + idx;
+      for (;;) {
+        const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          return w;
+        }
+        if (overdue()) return 0;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    q = (q + 1) & 7;
+    --left;
+  }
+  return 0;
+}
+
+// wave 0 after the tile's stores are released: arrivals and announcements (sched_logic.h: finish, with the two fan-outs
+// spread over the lanes)
+__device__ inline void sched_finish(const SchedArgs& a, const sched::Shape& s, unsigned long long w, int lane) {
+  const int kind = sched::task_kind(w), j = sched::task_j(w), i = sched::task_i(w), b = sched::task_b(w);
+  const int R = sched::rows(s);
+  int* c = a.counters + (size_t)b * sched::counters_per_matrix(s);
+  int* ctl = a.ctrl + (b & 7) * 16;
+  unsigned long long* slots = a.slots + (size_t)ctl[3];
+  auto add = [&](int idx, int inc) { return __hip_atomic_fetch_add(c + idx, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto announce = [&](int k2, int j2, int i2) {
+    const int pos = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slots + pos, sched::encode(k2, j2, i2, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  const bool pivot = kind == sched::kT && i == j + 1 && j + 1 < s.nt;
+  if (kind == sched::kD || pivot) {
+    if (pivot) {                                          // D(j+1) first: it is the longest task that follows
+      bool rd = false;
+      if (lane == 0) rd = sched::lo16(add(2 * R, 1 << 16)) >= j + 1;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      if (rd) announce(sched::kD, j + 1, j + 1);
+    }
+    const int r0 = kind == sched::kD ? j + 1 : j + 2;
+    for (int rb = r0; rb < R; rb += 64) {                 // wave-uniform trip count: the fence below is executed by every lane
+      const int r = rb + lane;
+      bool rd = false;
+      if (r < R) rd = kind == sched::kD ? sched::row_after_D(s, j, r, add) : sched::row_after_pivot(s, j, r, add);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      if (rd) announce(kind == sched::kD ? sched::kT : sched::kU, kind == sched::kD ? j : j + 1, r);
+    }
+  } else if (lane == 0) {
+    // one arrival, at most one announcement: the shared single-thread rule, with the fence between the two
+    int ak = 0, aj = 0, ai = 0;
+    sched::finish(s, kind, j, i, add, [&](int k2, int j2, int i2) { ak = k2; aj = j2; ai = i2; });
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    if (ak) announce(ak, aj, ai);
+  }
+}
+
+__device__ __forceinline__ void sched_run(const GemmArgs& g, double* smem, unsigned long long w) {
+  const int kind = sched::task_kind(w), j = sched::task_j(w), i = sched::task_i(w), b = sched::task_b(w);
+  if (kind == sched::kD) {
+    if (j == 0) {
+      DiagArgs dg{g.A, g.a_stride, g.npad, g.invd, g.invd_stride, g.logdet_part, g.status, 0, g.nt, g.nb, g.n, g.ld, g.ptol};
+      diag_factor(dg, b, smem);
+    } else {
+      diag_unit(g, smem, j, b);
+    }
+  } else if (kind == sched::kU) {
+    gemm_unit<0, 1, false>(g, smem, j, b, i, 0, false);
+  } else {
+    gemm_unit<1, 1, false>(g, smem, j, b, i, 0, false);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void chol_sched_kernel(SchedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ unsigned long long s_task;
+  const int tid = threadIdx.x;
+  const sched::Shape shp{a.g.nt, a.g.ne, a.g.extra_lower};
+  int q = 0, left = 8, secondary = 0;
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7;      // XCC_ID
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID: cu [11:8], sh [12], se [15:13]
+    const int seen = __hip_atomic_fetch_add(a.cu_seen + xcc * 128 + ((hw >> 8) & 127), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q = (int)xcc;
+    secondary = (a.policy & 1) && seen > 0;
+  }
+  for (;;) {
+    if (tid == 0) s_task = sched_pop(a, q, left, secondary);
+    __syncthreads();
+    const unsigned long long wv = s_task;
+    const unsigned long long w = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(wv >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)wv);
+    if (w == 0) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave: what the producers released is read afresh
+    sched_run(a.g, smem, w);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every wave: its stores are visible device-wide before the barrier
+    __syncthreads();
+    if (tid < 64) sched_finish(a, shp, w, tid);
+  }
+}
+
+// counters, queue heads / tails / sizes / offsets, seeds D(0) and empty slots for one sweep
+struct SchedInitArgs {
+  int* ctrl;
+  unsigned long long* slots;
+  int* counters;
+  int* cu_seen;
+  int nb, nt, ne, lower;
+  long tasks_per_matrix;
+  long total_slots;
+};
+__global__ __launch_bounds__(256) void sched_init_kernel(SchedInitArgs a) {
+  const sched::Shape s{a.nt, a.ne, a.lower};
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+  const int cpm = sched::counters_per_matrix(s);
+  // matrices of queue q: b = q, q + 8, ...; its slots start at off(q)
+  auto nmat = [&](int q) { return a.nb > q ? (a.nb - q + 7) / 8 : 0; };
+  auto off = [&](int q) { long o = 0; for (int x = 0; x < q; ++x) o += nmat(x) * a.tasks_per_matrix; return o; };
+  for (long e = tid; e < a.total_slots; e += nth) a.slots[e] = 0;
+  for (long e = tid; e < 8 * 128; e += nth) a.cu_seen[e] = 0;
+  for (long e = tid; e < kSchedCtrlInts; e += nth) {
+    const int q = (int)(e >> 4), f = (int)(e & 15);
+    int v = 0;
+    if (q < 8 && f == 1) v = nmat(q);                                // tail: the seeds
+    if (q < 8 && f == 2) v = (int)(nmat(q) * a.tasks_per_matrix);
+    if (q < 8 && f == 3) v = (int)off(q);
+    a.ctrl[e] = v;
+  }
+  for (long b = tid; b < a.nb; b += nth) sched::init_counters(s, a.counters + b * cpm);
+  __syncthreads();
+  // seeds after the zeroing of THEIR slots: the first nmat(q) slots of a queue are written by the threads below only
+  // (the zeroing loop above skips nothing, so order the two through a second pass: seeds are stored by the same grid-stride
+  // owner that zeroed the slot)
+  for (long e = tid; e < a.total_slots; e += nth) {
+    int q = 0;
+    long o = 0;
+    while (q < 7 && e >= o + nmat(q) * a.tasks_per_matrix) { o += nmat(q) * a.tasks_per_matrix; ++q; }
+    const long k = e - o;
+    if (k < nmat(q)) a.slots[e] = sched::encode(sched::kD, 0, 0, (int)(q + 8 * k));
+  }
+}
+
+// after the sweep: an aborted schedule fails every matrix of the chunk (status -> NaN likelihoods, non-zero return code)
+__global__ void sched_check_kernel(const int* ctrl, int* status, int nb) {
+  if (sched_ld(ctrl + 128) == 0) return;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) status[b] = 0x7fffffff;
+}
 
 // Strip count of an update launch: always 1 since round 2.  One workgroup per SIMD-set saturates a CU's four MFMA
 // pipes, so the time of a launch is a step function of its workgroup count in units of 256 (16.3 us per 128-deep
@@ -1788,7 +2019,13 @@ size_t blocked_ws_bytes(int npad, int nb, int ne) {
   size_t dbl = (size_t)nb * (npad + kTile * (1 + ne)) * npad + (size_t)nb * nt * kTile * kTile +
                (size_t)nb * (nt + 2) + 64 + (size_t)npad * kMaxD + 16 +
                (size_t)nb * kMaxK * npad + 16;   // upad
-  return dbl * sizeof(double);
+  return dbl * sizeof(double) + sched_ws_bytes(nt, nb, ne);
+}
+
+// scratch of the dataflow scheduler: task slots (8 B per task), counters, queue control block, per-CU registration
+size_t sched_ws_bytes(int nt, int nb, int ne) {
+  const sched::Shape s{nt, ne, 0};   // identity rows (lower) only take tasks away: an upper bound
+  return 8 * (size_t)nb * (size_t)sched::tasks_per_matrix(s) + 4 * ((size_t)nb * sched::counters_per_matrix(s) + kSchedCtrlInts + 8 * 128) + 64;
 }
 
 BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
@@ -1803,6 +2040,7 @@ BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
   w.fin = w.z + (size_t)nb * nt;
   w.xpad = w.fin + (((size_t)2 * nb + 15) & ~(size_t)15);   // 128-byte aligned: whole s_load_dwordx16 lines
   w.upad = w.xpad + (size_t)npad * kMaxD;
+  w.sched = w.upad + (size_t)nb * kMaxK * npad + 16;
   return w;
 }
 
@@ -1990,11 +2228,42 @@ struct GroupRun {
     }
   }
 
+  // The whole factorisation of the chunk as one persistent launch (chol_sched_kernel).  Needs what the launches' default
+  // configuration has: whole update tiles and the diagonal workgroup that factorises its block.
+  bool scheduled() const {
+    return h->opt_sched && h->opt_fuse_diag && !any_fused && force_s == 0 && sched::rows(sched::Shape{nt, w.ne, 0}) < 0x7fff &&
+           (size_t)nb * (size_t)sched::tasks_per_matrix(sched::Shape{nt, w.ne, 0}) < 0x7fffffffull;
+  }
+  void sweep_scheduled() {
+    ScopedTimer t(h, CCGP_T_SWEEP, s);
+    const sched::Shape shp{nt, w.ne, g.extra_lower};
+    const long tpm = sched::tasks_per_matrix(shp), total = tpm * nb;
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(w.sched);
+    int* counters = reinterpret_cast<int*>(slots + (size_t)nb * sched::tasks_per_matrix(sched::Shape{nt, w.ne, 0}));
+    int* ctrl = counters + (size_t)nb * sched::counters_per_matrix(shp);
+    int* cu_seen = ctrl + kSchedCtrlInts;
+    SchedInitArgs ia{ctrl, slots, counters, cu_seen, nb, nt, w.ne, g.extra_lower, tpm, total};
+    const int init_blocks = (int)std::min<long>(2048, (total + 255) / 256 + 8);
+    hipLaunchKernelGGL(sched_init_kernel, dim3(init_blocks), dim3(256), 0, s, ia);
+    SchedArgs a{};
+    a.g = g; a.g.j = 0; a.g.mode = 0; a.g.fuse_gen = 0; a.g.n_s1 = 0; a.g.tail_s = 2;
+    a.ctrl = ctrl; a.slots = slots; a.counters = counters; a.cu_seen = cu_seen;
+    a.policy = h->opt_sched_policy;
+    a.timeout_10ns = h->sched_timeout_ms >= 40000 ? 4000000000u : (unsigned)h->sched_timeout_ms * 100000u;
+    const int wgs = h->n_cus * (h->opt_sched == 1 ? 2 : 1);
+    hipLaunchKernelGGL(chol_sched_kernel, dim3(wgs), dim3(256), gemm_lds_bytes<1>(), s, a);
+    hipLaunchKernelGGL(sched_check_kernel, dim3(1), dim3(256), 0, s, ctrl, status + b0, nb);
+  }
+
   void run_all() {
     begin();
-    for (int j = 0; j < nt; ++j) {
-      update(j);
-      panel(j);
+    if (scheduled()) {
+      sweep_scheduled();
+    } else {
+      for (int j = 0; j < nt; ++j) {
+        update(j);
+        panel(j);
+      }
     }
     finish();
   }
@@ -2015,6 +2284,7 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
     raise_lds_limit((const void*)chol_update_gen_kernel, "chol_update_gen_kernel");
     raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
     raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
+    raise_lds_limit((const void*)chol_sched_kernel, "chol_sched_kernel");
     raise_lds_limit((const void*)rinv_tile_kernel<false>, "rinv_tile_kernel<false>");
     raise_lds_limit((const void*)rinv_tile_kernel<true>, "rinv_tile_kernel<true>");
     raise_lds_limit((const void*)grad_contract_kernel<4>, "grad_contract_kernel<4>");

@@ -500,6 +500,12 @@ int ccgp_create(int device, ccgp_handle** out) {
   // n = 4096 grid of BASELINE config 4 is 73 GB and runs as ONE chunk)
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) h->ws_limit = total_b / 4 * 3;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
+  if (const char* e = std::getenv("CCGP_SCHED_TIMEOUT_MS")) {
+    const int v = std::atoi(e);
+    if (v > 0) h->sched_timeout_ms = v;
+  }
   *out = h;
   return CCGP_OK;
 }
@@ -579,6 +585,14 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
   }
   if (option == CCGP_OPT_FUSED_COV && (value == 0 || value == 1)) {
     h->opt_fused_cov = value;
+    return CCGP_OK;
+  }
+  if (option == CCGP_OPT_SCHED && value >= 0 && value <= 2) {
+    h->opt_sched = value;
+    return CCGP_OK;
+  }
+  if (option == CCGP_OPT_SCHED_POLICY && value >= 0 && value <= 1) {
+    h->opt_sched_policy = value;
     return CCGP_OK;
   }
   return fail(h, CCGP_EINVAL, "ccgp_set_option: unknown option or value");

@@ -78,6 +78,10 @@ struct ccgp_handle {
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
   int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
+  int opt_sched = 1;                    // CCGP_OPT_SCHED: 0 = one launch per phase and block column, 1 = dataflow scheduler with two workgroups per CU, 2 = with one
+  int opt_sched_policy = 1;             // CCGP_OPT_SCHED_POLICY bit 0: a CU's second workgroup only takes work while a backlog exists
+  int sched_timeout_ms = 30000;         // a scheduler wait longer than this aborts the sweep (CCGP_SCHED_TIMEOUT_MS)
+  int n_cus = 256;                      // multiProcessorCount of the handle's device
   // grow-only device scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;
@@ -171,6 +175,7 @@ struct BlockedWs {
   double* fin;      // nb x 2: s11 = 1'R^-1 1 and beta per matrix (prediction pass)
   double* xpad;     // npad x kMaxD: the design zero-padded to npad rows (scalar-load source of cov_kernel's columns)
   double* upad;     // nb x kMaxK x npad: u[z][c][i] = sum_k theta_ck x_ik^2 (round 4: shared by cov_kernel and the update)
+  double* sched;    // scratch of the dataflow scheduler (sched_ws_bytes): task slots, counters, queue control
   size_t a_stride;  // elements between consecutive matrices
   int ld;           // npad + 128 * (1 + ne)
   int ne;           // extra full tile rows (ceil(m / 128) for prediction, else 0)
@@ -197,6 +202,7 @@ struct BlockedJob {
 bool blocked_grad_supported(int d, int K);
 size_t blocked_grad_partials(int npad);   // partial sums per matrix and parameter (gpart = nb x this x P)
 size_t blocked_ws_bytes(int npad, int nb, int ne);
+size_t sched_ws_bytes(int nt, int nb, int ne);
 BlockedWs blocked_carve(void* ws, int npad, int nb, int ne);
 // factorise nb matrices in place and finish the likelihood; loglik/beta/status are
 // indexed from draw b0.

@@ -111,8 +111,14 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           reads them; 1 = whole tiles of the update generate their covariance tile in their own epilogue
  *                           and cov_kernel writes only the rest (same bits: the tests hold one against the other; a third
  *                           less HBM traffic per evaluation at n = 4096 for 0.3 - 0.6 % of its time) */
+/*   CCGP_OPT_SCHED          1 (default) = the blocked Cholesky sweep of a chunk (n > 128) is ONE persistent launch whose workgroups
+ *                           take diagonal / update / panel-solve tiles from dependency-driven queues (two workgroups per CU);
+ *                           2 = the same with one workgroup per CU; 0 = one launch per phase and block column (rounds 1 - 4).
+ *                           Same tile code and summation order: same bits.
+ *   CCGP_OPT_SCHED_POLICY   1 (default) = a CU's second workgroup only takes a tile while ready tiles are waiting; 0 = always */
 enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3,
-       CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5, CCGP_OPT_FUSED_COV = 6 };
+       CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5, CCGP_OPT_FUSED_COV = 6, CCGP_OPT_SCHED = 7,
+       CCGP_OPT_SCHED_POLICY = 8 };
 int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);
@@ -289,7 +295,8 @@ enum {
   CCGP_T_TRSM = 3,     /* panel triangular solve (MFMA)     */
   CCGP_T_SOLVE = 4,    /* forward solves + reductions       */
   CCGP_T_FUSED = 5,    /* small-n fused in-LDS evaluator    */
-  CCGP_T_COUNT = 6
+  CCGP_T_SWEEP = 6,    /* blocked Cholesky sweep as one scheduled launch (update + diag + trsm tiles) */
+  CCGP_T_COUNT = 7
 };
 /* on = 0: off; 1: every id; otherwise a mask with bit (1 + id) set for each id to time */
 int ccgp_enable_timing(ccgp_handle* h, int on);

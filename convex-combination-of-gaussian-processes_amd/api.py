@@ -85,6 +85,7 @@ SIGNATURES = {
                                          c_double, _dp, _dp, _dp, _ip]),
     "ccgp_enable_timing": (c_int, [c_void_p, c_int]),
     "ccgp_get_timing": (c_int, [c_void_p, c_int, _dp, _ip]),
+    "ccgp_last_sched_profile": (c_int, [c_void_p, c_void_p, c_int, _ip]),
     "ccgp_last_sweep_plan": (c_int, [c_void_p, _ip, _ip]),
 }
 
@@ -340,6 +341,16 @@ class Handle:
             ms, cnt = c_double(), c_int()
             self._chk(lib().ccgp_get_timing(self._h, i, ctypes.byref(ms), ctypes.byref(cnt)))
             out[name] = (ms.value, cnt.value)
+        return out
+
+    def last_sched_profile(self):
+        """Per-workgroup time account of the last scheduled sweep (OPT_SCHED_POLICY bit 2): array (workgroups, 8) --
+        microseconds waiting for a task, in D / U / T tiles, applying arrivals; tasks run; XCD served; second-on-its-CU."""
+        buf = np.zeros((1024, 8), dtype=np.uint64)
+        nw = c_int()
+        self._chk(lib().ccgp_last_sched_profile(self._h, buf.ctypes.data_as(c_void_p), 1024, ctypes.byref(nw)))
+        out = buf[:nw.value].astype(np.float64)
+        out[:, :5] *= 0.01
         return out
 
     def last_sweep_plan(self):

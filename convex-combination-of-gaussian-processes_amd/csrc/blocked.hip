@@ -1280,30 +1280,56 @@ CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2, false)
 //            every workgroup leaves -- the sweep then reports failure for the chunk instead of hanging the device)
 //   finish : every wave releases its stores at agent scope, barrier, then wave 0 applies the arrivals (one lane per row for the
 //            fan-outs of a diagonal block and of a pivot-row solve) and stores the tasks that became ready
-// Memory model: tile data crosses workgroups only through  release fence (agent) -> relaxed RMW / store  on one side and
-// relaxed load -> acquire fence (agent)  on the other; a counter's last arriver fences acq_rel between its RMW and its
-// announcement, so earlier arrivers' tiles are visible to whoever runs the announced task.
+// Synchronisation, two forms (policy bit 1):
+//   agent (0) : the HSA memory model as the compiler implements it -- release fence (agent) -> relaxed RMW / store on one side,
+//               relaxed load -> acquire fence (agent) on the other; a counter's last arriver fences acq_rel between its RMW and
+//               its announcement.  On this chip an agent-scope acquire is `buffer_inv sc1` and a release `buffer_wbl2 sc1`: every
+//               task invalidates and writes back the L2 of its XCD, the column panel that a matrix's tiles share through that L2
+//               is re-read from HBM by every tile, and the sweep takes 269 ms instead of 189 (profiles/r05_experiments.md).
+//   xcd (1, default) : everything that touches a matrix runs on ONE XCD (its queue is served by that XCD's workgroups only: no
+//               stealing), so producer and consumer share the L2 and only the per-CU L1 stands between them.  L1 is write-through:
+//               `s_waitcnt vmcnt(0)` = the stores are in L2; `buffer_inv sc0` drops the consumer's L1 lines; counters and queue
+//               words are L2 atomics / L1-bypassing loads.  The queues of XCDs that got no workgroup would never drain: the check
+//               kernel fails the chunk unless every queue announced all of its tasks.
 // Placement: a workgroup serves the queue of the XCD it runs on (XCC_ID), so a matrix's tiles share the column panel in one
-// L2 as they do under the launches' blockIdx % 8 rule; when its queue is handed out it moves on to the next one, so every
-// queue is drained wherever the workgroups landed.  Two workgroups fit a CU; with `policy` bit 0 the second one of a CU only
-// takes work while a backlog exists (tail > head), so that a few ready tiles spread over the CUs instead of pairing up.
+// L2 as they do under the launches' blockIdx % 8 rule; in agent form a workgroup whose queue is handed out moves on to the next
+// one.  Two workgroups fit a CU; with `policy` bit 0 the second one of a CU only takes work while a backlog exists
+// (tail > head), so that a few ready tiles spread over the CUs instead of pairing up.
 struct SchedArgs {
   GemmArgs g;
-  int* ctrl;                     // [q * 16 + 0] head, [+1] tail, [+2] tasks of queue q, [+3] slot offset; [128] abort, [129] longest wait (10 ns)
+  int* ctrl;                     // [q * 16 + 0] head, [+1] tail, [+2] tasks of queue q, [+3] slot offset, [+4] tasks finished; [128] abort
   unsigned long long* slots;
   int* counters;                 // nb x counters_per_matrix
   int* cu_seen;                  // [8 * 128]: workgroups that registered on each CU
   int policy;
+  int backlog_min;               // policy bit 0: a CU's second workgroup takes (or chains) a task only while at least this many wait in its queue
   unsigned timeout_10ns;         // a wait longer than this aborts the sweep
+  unsigned long long* prof;      // policy bit 2: per workgroup 8 words (10 ns ticks): waiting for a task, D, U, T tiles, arrivals; tasks, XCD, second-on-its-CU
 };
 constexpr int kSchedCtrlInts = 256;
+constexpr int kSchedProfWgs = 1024, kSchedProfWords = 8;
 
-__device__ __forceinline__ int sched_ld(const int* p) {
+__device__ __forceinline__ int sched_ld(const int* p) {   // sc1 load: never served by the L1
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void sched_acquire(bool xcd) {
+  if (xcd) asm volatile("buffer_inv sc0" ::: "memory");
+  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void sched_release(bool xcd) {
+  if (xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+__device__ __forceinline__ void sched_acq_rel(bool xcd) {
+  if (xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+}
 
-// thread 0: next task word of this workgroup, or 0 when every queue is handed out (or the sweep was aborted)
+// thread 0: next task word of this workgroup, or 0 when its queue(s) are finished (or the sweep was aborted).
+// A queue is finished when all of its tasks are DONE (ctl[4] == N): tasks that a workgroup chained to the one it had just
+// finished never pass through a slot, so fewer than N slots are ever filled and the holders of the others leave on that count.
 __device__ inline unsigned long long sched_pop(const SchedArgs& a, int& q, int& left, int secondary) {
+  const bool xcd = (a.policy & 2) != 0;
   while (left > 0) {
     int* ctl = a.ctrl + q * 16;
     const int N = ctl[2];
@@ -1320,27 +1346,32 @@ __device__ inline unsigned long long sched_pop(const SchedArgs& a, int& q, int& 
       }
       return false;
     };
-    if (secondary && N > 0) {
+    bool live = N > 0;
+    if (live && secondary) {
       for (;;) {
-        const int hd = sched_ld(ctl), tl = sched_ld(ctl + 1);
-        if (hd >= N || tl > hd) break;
+        if (sched_ld(ctl + 4) >= N) { live = false; break; }
+        if (sched_ld(ctl + 1) - sched_ld(ctl) >= a.backlog_min) break;
         if (overdue()) return 0;
         __builtin_amdgcn_s_sleep(8);
       }
     }
-    const int idx = N > 0 ? __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    if (idx < N) {
-      const unsigned long long* slot = a.slots + (size_t)ctl[3] + idx;
-      for (;;) {
-        const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          return w;
+    if (live) {
+      const int idx = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (idx < N) {
+        const unsigned long long* slot = a.slots + (size_t)ctl[3] + idx;
+        for (;;) {
+          const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (w) {
+            sched_acquire(xcd);
+            return w;
+          }
+          if ((polls & 7u) == 7u && sched_ld(ctl + 4) >= N) break;   // everything is done: this slot stays empty
+          if (overdue()) return 0;
+          __builtin_amdgcn_s_sleep(2);
         }
-        if (overdue()) return 0;
-        __builtin_amdgcn_s_sleep(2);
       }
     }
+    if (xcd) return 0;   // no stealing: another XCD's tiles must not pass through this L2
     q = (q + 1) & 7;
     --left;
   }
@@ -1348,15 +1379,22 @@ __device__ inline unsigned long long sched_pop(const SchedArgs& a, int& q, int& 
 }
 
 // wave 0 after the tile's stores are released: arrivals and announcements (sched_logic.h: finish, with the two fan-outs
-// spread over the lanes)
-__device__ inline void sched_finish(const SchedArgs& a, const sched::Shape& s, unsigned long long w, int lane) {
+// spread over the lanes).  Returns (lane 0) the task this workgroup goes on with itself -- the first one its arrivals made
+// ready, in the order of urgency: the next diagonal block, the pivot row's solve, the row's own next tile -- or 0.
+__device__ inline unsigned long long sched_finish(const SchedArgs& a, const sched::Shape& s, unsigned long long w, int lane, bool chain) {
   const int kind = sched::task_kind(w), j = sched::task_j(w), i = sched::task_i(w), b = sched::task_b(w);
   const int R = sched::rows(s);
+  const bool xcd = (a.policy & 2) != 0;
   int* c = a.counters + (size_t)b * sched::counters_per_matrix(s);
   int* ctl = a.ctrl + (b & 7) * 16;
   unsigned long long* slots = a.slots + (size_t)ctl[3];
+  unsigned long long next = 0;
   auto add = [&](int idx, int inc) { return __hip_atomic_fetch_add(c + idx, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto announce = [&](int k2, int j2, int i2) {
+  auto emit = [&](int k2, int j2, int i2) {
+    if (chain && lane == 0 && next == 0) {
+      next = sched::encode(k2, j2, i2, b);
+      return;
+    }
     const int pos = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(slots + pos, sched::encode(k2, j2, i2, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -1365,24 +1403,26 @@ __device__ inline void sched_finish(const SchedArgs& a, const sched::Shape& s, u
     if (pivot) {                                          // D(j+1) first: it is the longest task that follows
       bool rd = false;
       if (lane == 0) rd = sched::lo16(add(2 * R, 1 << 16)) >= j + 1;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-      if (rd) announce(sched::kD, j + 1, j + 1);
+      sched_acq_rel(xcd);
+      if (rd) emit(sched::kD, j + 1, j + 1);
     }
     const int r0 = kind == sched::kD ? j + 1 : j + 2;
     for (int rb = r0; rb < R; rb += 64) {                 // wave-uniform trip count: the fence below is executed by every lane
       const int r = rb + lane;
       bool rd = false;
       if (r < R) rd = kind == sched::kD ? sched::row_after_D(s, j, r, add) : sched::row_after_pivot(s, j, r, add);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-      if (rd) announce(kind == sched::kD ? sched::kT : sched::kU, kind == sched::kD ? j : j + 1, r);
+      sched_acq_rel(xcd);
+      if (rd) emit(kind == sched::kD ? sched::kT : sched::kU, kind == sched::kD ? j : j + 1, r);
     }
   } else if (lane == 0) {
     // one arrival, at most one announcement: the shared single-thread rule, with the fence between the two
     int ak = 0, aj = 0, ai = 0;
     sched::finish(s, kind, j, i, add, [&](int k2, int j2, int i2) { ak = k2; aj = j2; ai = i2; });
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-    if (ak) announce(ak, aj, ai);
+    sched_acq_rel(xcd);
+    if (ak) emit(ak, aj, ai);
   }
+  if (lane == 0) (void)__hip_atomic_fetch_add(ctl + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // after the announcements
+  return next;
 }
 
 __device__ __forceinline__ void sched_run(const GemmArgs& g, double* smem, unsigned long long w) {
@@ -1403,10 +1443,11 @@ __device__ __forceinline__ void sched_run(const GemmArgs& g, double* smem, unsig
 
 __global__ __launch_bounds__(256, 2) void chol_sched_kernel(SchedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ unsigned long long s_task;
+  __shared__ unsigned long long s_task, s_next, s_acc[6];   // thread 0's state lives in LDS: registers are the tiles'
   const int tid = threadIdx.x;
   const sched::Shape shp{a.g.nt, a.g.ne, a.g.extra_lower};
   int q = 0, left = 8, secondary = 0;
+  const bool xcd = (a.policy & 2) != 0;
   if (tid == 0) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7;      // XCC_ID
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID: cu [11:8], sh [12], se [15:13]
@@ -1414,18 +1455,51 @@ __global__ __launch_bounds__(256, 2) void chol_sched_kernel(SchedArgs a) {
     q = (int)xcc;
     secondary = (a.policy & 1) && seen > 0;
   }
+  const bool prof = (a.policy & 4) && a.prof && blockIdx.x < kSchedProfWgs;
+  const bool chaining = (a.policy & 8) != 0;
+  if (tid == 0) {
+    s_next = 0;   // the task this workgroup chained to the one it finished
+    for (int e = 0; e < 6; ++e) s_acc[e] = 0;
+  }
   for (;;) {
-    if (tid == 0) s_task = sched_pop(a, q, left, secondary);
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (prof && tid == 0) t0 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      const unsigned long long nx = s_next;
+      s_task = nx ? nx : sched_pop(a, q, left, secondary);
+    }
     __syncthreads();
     const unsigned long long wv = s_task;
     const unsigned long long w = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(wv >> 32)) << 32) |
                                  (unsigned)__builtin_amdgcn_readfirstlane((int)wv);
     if (w == 0) break;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave: what the producers released is read afresh
+    sched_acquire(xcd);   // every wave: what the producers released is read afresh
+    if (prof && tid == 0) t1 = __builtin_amdgcn_s_memrealtime();
     sched_run(a.g, smem, w);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every wave: its stores are visible device-wide before the barrier
+    sched_release(xcd);   // every wave: its stores are out (in L2, or device-wide) before the barrier
     __syncthreads();
-    if (tid < 64) sched_finish(a, shp, w, tid);
+    if (prof && tid == 0) t2 = __builtin_amdgcn_s_memrealtime();
+    if (tid < 64) {
+      bool chain = chaining;
+      if (chain && secondary) {   // a CU's second workgroup goes on only while its queue has a backlog
+        const int* ctl = a.ctrl + (sched::task_b(w) & 7) * 16;
+        chain = sched_ld(ctl + 1) - sched_ld(ctl) >= a.backlog_min;
+      }
+      const unsigned long long nx = sched_finish(a, shp, w, tid, chain);
+      if (tid == 0) s_next = nx;
+    }
+    if (prof && tid == 0) {
+      s_acc[0] += t1 - t0;
+      s_acc[sched::task_kind(w)] += t2 - t1;
+      s_acc[4] += __builtin_amdgcn_s_memrealtime() - t2;
+      s_acc[5] += 1;
+    }
+  }
+  if (prof && tid == 0) {
+    unsigned long long* o = a.prof + (size_t)blockIdx.x * kSchedProfWords;
+    for (int e = 0; e < 6; ++e) o[e] = s_acc[e];
+    o[6] = (unsigned long long)q;
+    o[7] = (unsigned long long)secondary;
   }
 }
 
@@ -1470,9 +1544,12 @@ __global__ __launch_bounds__(256) void sched_init_kernel(SchedInitArgs a) {
   }
 }
 
-// after the sweep: an aborted schedule fails every matrix of the chunk (status -> NaN likelihoods, non-zero return code)
+// after the sweep: an aborted or incomplete schedule (a queue nobody served) fails every matrix of the chunk (status -> NaN
+// likelihoods, non-zero return code)
 __global__ void sched_check_kernel(const int* ctrl, int* status, int nb) {
-  if (sched_ld(ctrl + 128) == 0) return;
+  bool ok = sched_ld(ctrl + 128) == 0;
+  for (int q = 0; q < 8; ++q) ok = ok && sched_ld(ctrl + q * 16 + 4) == ctrl[q * 16 + 2];   // every task of every queue was run
+  if (ok) return;
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) status[b] = 0x7fffffff;
 }
 
@@ -2025,7 +2102,8 @@ size_t blocked_ws_bytes(int npad, int nb, int ne) {
 // scratch of the dataflow scheduler: task slots (8 B per task), counters, queue control block, per-CU registration
 size_t sched_ws_bytes(int nt, int nb, int ne) {
   const sched::Shape s{nt, ne, 0};   // identity rows (lower) only take tasks away: an upper bound
-  return 8 * (size_t)nb * (size_t)sched::tasks_per_matrix(s) + 4 * ((size_t)nb * sched::counters_per_matrix(s) + kSchedCtrlInts + 8 * 128) + 64;
+  return 8 * (size_t)nb * (size_t)sched::tasks_per_matrix(s) + 4 * ((size_t)nb * sched::counters_per_matrix(s) + kSchedCtrlInts + 8 * 128) + 64 +
+         8 * (size_t)kSchedProfWgs * kSchedProfWords;
 }
 
 BlockedWs blocked_carve(void* ws, int npad, int nb, int ne) {
@@ -2230,8 +2308,17 @@ struct GroupRun {
 
   // The whole factorisation of the chunk as one persistent launch (chol_sched_kernel).  Needs what the launches' default
   // configuration has: whole update tiles and the diagonal workgroup that factorises its block.
+  // CCGP_OPT_SCHED 3 (default) chooses by measurement (profiles/r05_experiments.md, n = 4096, same box, chunk sizes 8 ... 512):
+  // the scheduler with one workgroup per CU is ahead where the launches lose CUs to their partial last steps and to the late
+  // block columns -- 32 ... 128 matrices, the share of one GPU when the 512-point grid is spread over 4 - 8 of them
+  // (64 matrices: 26.25 against 26.93 ms) -- and behind by 1.5 - 2.5 % on both sides of that: few matrices (critical path:
+  // queue hops instead of launches) and many (whole steps: nothing to recover, and the queue traffic costs 2.4 us per task).
+  int sched_mode() const {
+    if (h->opt_sched != 3) return h->opt_sched;
+    return (nt >= 16 && nb >= 32 && nb <= 128) ? 2 : 0;
+  }
   bool scheduled() const {
-    return h->opt_sched && h->opt_fuse_diag && !any_fused && force_s == 0 && sched::rows(sched::Shape{nt, w.ne, 0}) < 0x7fff &&
+    return sched_mode() != 0 && h->opt_fuse_diag && !any_fused && force_s == 0 && sched::rows(sched::Shape{nt, w.ne, 0}) < 0x7fff &&
            (size_t)nb * (size_t)sched::tasks_per_matrix(sched::Shape{nt, w.ne, 0}) < 0x7fffffffull;
   }
   void sweep_scheduled() {
@@ -2242,6 +2329,7 @@ struct GroupRun {
     int* counters = reinterpret_cast<int*>(slots + (size_t)nb * sched::tasks_per_matrix(sched::Shape{nt, w.ne, 0}));
     int* ctrl = counters + (size_t)nb * sched::counters_per_matrix(shp);
     int* cu_seen = ctrl + kSchedCtrlInts;
+    h->sched_prof_dev = reinterpret_cast<unsigned long long*>(cu_seen + 8 * 128 + ((8 * 128 + kSchedCtrlInts + (size_t)nb * sched::counters_per_matrix(shp)) & 1));
     SchedInitArgs ia{ctrl, slots, counters, cu_seen, nb, nt, w.ne, g.extra_lower, tpm, total};
     const int init_blocks = (int)std::min<long>(2048, (total + 255) / 256 + 8);
     hipLaunchKernelGGL(sched_init_kernel, dim3(init_blocks), dim3(256), 0, s, ia);
@@ -2249,8 +2337,11 @@ struct GroupRun {
     a.g = g; a.g.j = 0; a.g.mode = 0; a.g.fuse_gen = 0; a.g.n_s1 = 0; a.g.tail_s = 2;
     a.ctrl = ctrl; a.slots = slots; a.counters = counters; a.cu_seen = cu_seen;
     a.policy = h->opt_sched_policy;
+    a.backlog_min = h->sched_backlog_min > 0 ? h->sched_backlog_min : std::max(1, h->n_cus / 8);
+    a.prof = h->sched_prof_dev;
     a.timeout_10ns = h->sched_timeout_ms >= 40000 ? 4000000000u : (unsigned)h->sched_timeout_ms * 100000u;
-    const int wgs = h->n_cus * (h->opt_sched == 1 ? 2 : 1);
+    const int wgs = h->n_cus * (sched_mode() == 1 ? 2 : 1);
+    h->sched_prof_wgs = wgs < kSchedProfWgs ? wgs : kSchedProfWgs;
     hipLaunchKernelGGL(chol_sched_kernel, dim3(wgs), dim3(256), gemm_lds_bytes<1>(), s, a);
     hipLaunchKernelGGL(sched_check_kernel, dim3(1), dim3(256), 0, s, ctrl, status + b0, nb);
   }

@@ -314,36 +314,47 @@ __device__ inline double wg4_sum(double x, double (&red)[4], int tid) {
 
 __global__ __launch_bounds__(256) void rinv_terms_kernel(const double* Rinv, const double* y, int n, double beta,
                                                          double* mean_factor, double* colsum, double* scal) {
-  // one workgroup; scal[0] = 1'Rinv y, scal[1] = sum(Rinv), scal[2] = (y-b)'Rinv(y-b)
-  __shared__ double part[2][4][64];
+  // one workgroup; scal[0] = 1'Rinv y, scal[1] = sum(Rinv), scal[2] = (y-b)'Rinv(y-b).
+  // The caller's R.Inv is taken as it is, symmetric or not (R's solve() output is symmetric only up to rounding):
+  // var.factor1 = apply(R.Inv, 2, sum) are COLUMN sums (HX:609), 1'R.Inv y = sum_j colsum_j y_j (HX:387), and
+  // mean.factor = R.Inv %*% (y - beta) are row dot products (HX:608).
+  __shared__ double part[4][64];
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   for (int i0 = 0; i0 < n; i0 += 64) {
-    // rows i0 .. i0 + 63: row sums (= column sums: R.Inv is symmetric, apply(R.Inv, 2, sum)) and (R.Inv (y - beta))_i
+    // rows i0 .. i0 + 63: (R.Inv (y - beta))_i, lane = row (a column of R.Inv is contiguous), the waves share the columns
     const int i = i0 + lane;
-    double cs = 0.0, mf = 0.0;
+    double mf = 0.0;
     if (i < n) {
 #pragma unroll 4
-      for (int j = wave; j < n; j += 4) {
-        const double v = Rinv[i + (size_t)j * n];
-        cs += v;
-        mf = fma(v, y[j] - beta, mf);
-      }
+      for (int j = wave; j < n; j += 4) mf = fma(Rinv[i + (size_t)j * n], y[j] - beta, mf);
     }
-    part[0][wave][lane] = cs;
-    part[1][wave][lane] = mf;
+    part[wave][lane] = mf;
     __syncthreads();
     if (wave == 0 && i < n) {
-      cs = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
-      mf = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
-      if (colsum) colsum[i] = cs;
+      mf = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
       if (mean_factor) mean_factor[i] = mf;
-      a0 += cs * y[i];
-      a1 += cs;
       a2 += (y[i] - beta) * mf;
     }
     __syncthreads();
+  }
+  // column sums: four lanes per column (rows i = q, q + 4, ...), combined in fixed order
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + (tid >> 2), q = tid & 3;
+    double cs = 0.0;
+    if (j < n) {
+      const double* col = Rinv + (size_t)j * n;
+#pragma unroll 4
+      for (int i = q; i < n; i += 4) cs += col[i];
+    }
+    cs += __shfl_xor(cs, 1, 64);
+    cs += __shfl_xor(cs, 2, 64);
+    if (j < n && q == 0) {
+      if (colsum) colsum[j] = cs;
+      a0 += cs * y[j];
+      a1 += cs;
+    }
   }
   a0 = wg4_sum(a0, red, tid);
   a1 = wg4_sum(a1, red, tid);
@@ -502,6 +513,7 @@ int ccgp_create(int device, ccgp_handle** out) {
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) h->ws_limit = total_b / 4 * 3;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
+  if (const char* e = std::getenv("CCGP_SCHED_BACKLOG")) h->sched_backlog_min = std::atoi(e);
   if (const char* e = std::getenv("CCGP_SCHED_TIMEOUT_MS")) {
     const int v = std::atoi(e);
     if (v > 0) h->sched_timeout_ms = v;
@@ -587,11 +599,11 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
     h->opt_fused_cov = value;
     return CCGP_OK;
   }
-  if (option == CCGP_OPT_SCHED && value >= 0 && value <= 2) {
+  if (option == CCGP_OPT_SCHED && value >= 0 && value <= 3) {
     h->opt_sched = value;
     return CCGP_OK;
   }
-  if (option == CCGP_OPT_SCHED_POLICY && value >= 0 && value <= 1) {
+  if (option == CCGP_OPT_SCHED_POLICY && value >= 0 && value <= 15) {
     h->opt_sched_policy = value;
     return CCGP_OK;
   }
@@ -643,6 +655,17 @@ int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches) t
   }
   if (out_ms) *out_ms = ms;
   if (out_launches) *out_launches = cnt;
+  return CCGP_OK;
+} CCGP_GUARD_END(h)
+
+int ccgp_last_sched_profile(ccgp_handle* h, unsigned long long* out, int max_workgroups, int* out_workgroups) try {
+  if (!h || !out || max_workgroups < 1) return CCGP_EINVAL;
+  CCGP_HIP(hipSetDevice(h->device));
+  CCGP_HIP(hipStreamSynchronize(h->stream));
+  const int nw = std::min(max_workgroups, h->sched_prof_wgs);
+  if (out_workgroups) *out_workgroups = nw;
+  if (nw > 0 && h->sched_prof_dev)
+    CCGP_HIP(hipMemcpy(out, h->sched_prof_dev, sizeof(unsigned long long) * 8 * (size_t)nw, hipMemcpyDeviceToHost));
   return CCGP_OK;
 } CCGP_GUARD_END(h)
 

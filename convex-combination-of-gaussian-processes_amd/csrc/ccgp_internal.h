@@ -78,10 +78,13 @@ struct ccgp_handle {
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
   int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
-  int opt_sched = 1;                    // CCGP_OPT_SCHED: 0 = one launch per phase and block column, 1 = dataflow scheduler with two workgroups per CU, 2 = with one
-  int opt_sched_policy = 1;             // CCGP_OPT_SCHED_POLICY bit 0: a CU's second workgroup only takes work while a backlog exists
+  int opt_sched = 3;                    // CCGP_OPT_SCHED: 0 = one launch per phase and block column, 1 = dataflow scheduler with two workgroups per CU, 2 = with one, 3 = by chunk size
+  int opt_sched_policy = 11;            // CCGP_OPT_SCHED_POLICY bit 0: a CU's second workgroup only takes work while a backlog exists; bit 1: XCD-local synchronisation
   int sched_timeout_ms = 30000;         // a scheduler wait longer than this aborts the sweep (CCGP_SCHED_TIMEOUT_MS)
+  int sched_backlog_min = 0;            // 0: one XCD's share of the CUs (CCGP_SCHED_BACKLOG overrides)
   int n_cus = 256;                      // multiProcessorCount of the handle's device
+  unsigned long long* sched_prof_dev = nullptr;   // where the last scheduled sweep left its per-workgroup time account (policy bit 2)
+  int sched_prof_wgs = 0;
   // grow-only device scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;

@@ -111,11 +111,17 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           reads them; 1 = whole tiles of the update generate their covariance tile in their own epilogue
  *                           and cov_kernel writes only the rest (same bits: the tests hold one against the other; a third
  *                           less HBM traffic per evaluation at n = 4096 for 0.3 - 0.6 % of its time) */
-/*   CCGP_OPT_SCHED          1 (default) = the blocked Cholesky sweep of a chunk (n > 128) is ONE persistent launch whose workgroups
- *                           take diagonal / update / panel-solve tiles from dependency-driven queues (two workgroups per CU);
- *                           2 = the same with one workgroup per CU; 0 = one launch per phase and block column (rounds 1 - 4).
+/*   CCGP_OPT_SCHED          the blocked Cholesky sweep of a chunk (n > 128): 0 = one launch per phase and block column
+ *                           (rounds 1 - 4); 1 = ONE persistent launch whose workgroups take diagonal / update / panel-solve
+ *                           tiles from dependency-driven queues, two workgroups per CU; 2 = the same with one workgroup per CU;
+ *                           3 (default) = 2 for chunks of 32 ... 128 matrices with n >= 2048, where it measures ahead, else 0.
  *                           Same tile code and summation order: same bits.
- *   CCGP_OPT_SCHED_POLICY   1 (default) = a CU's second workgroup only takes a tile while ready tiles are waiting; 0 = always */
+ *   CCGP_OPT_SCHED_POLICY   bit mask, default 11.  bit 0: a CU's second workgroup only takes a tile while ready tiles are waiting
+ *                           (0 = always); bit 1: tiles of a matrix stay on one XCD and synchronise through its L2 (L1
+ *                           invalidate + store completion); 0 = agent-scope release / acquire fences, which write back and
+ *                           invalidate that L2 per tile (same bits, 40 % slower: DESIGN.md K3); bit 2: keep the per-workgroup
+ *                           time account that ccgp_last_sched_profile reads; bit 3: a workgroup goes on with the first task its
+ *                           own arrivals made ready instead of queueing it */
 enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3,
        CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5, CCGP_OPT_FUSED_COV = 6, CCGP_OPT_SCHED = 7,
        CCGP_OPT_SCHED_POLICY = 8 };
@@ -225,7 +231,9 @@ int ccgp_predict_from_factorset(ccgp_handle* h, const ccgp_factorset* fs, const 
 size_t ccgp_factorset_bytes(const ccgp_factorset* fs);
 int ccgp_factorset_free(ccgp_handle* h, ccgp_factorset* fs);
 
-/* literal factors(): out = (mean.factor[n], var.factor1[n], var.factor2) */
+/* literal factors(): out = (mean.factor[n], var.factor1[n], var.factor2).  R_inv is taken as the caller gives it, symmetric
+ * or not (R's solve() output is symmetric only up to rounding): var.factor1 = apply(R.Inv, 2, sum) are COLUMN sums (HX:609),
+ * mean.factor = R.Inv %*% (y - beta) row products (HX:608); ccgp_beta_mle forms (1' R.Inv) y / sum(R.Inv) (HX:387) likewise. */
 int ccgp_factors(ccgp_handle* h, const double* R_inv, double beta, const double* y, int n,
                  double* out);
 /* literal predict.post arithmetic with caller-supplied cached terms (HX:667-670);
@@ -305,6 +313,10 @@ int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches);
  * whose trailing update generated its covariance tiles (0 unless CCGP_OPT_FUSED_COV) and the number of 64 x 64 tiles per matrix
  * left to the covariance kernel (all n_pad/64 (n_pad/64 + 1) / 2 lower tiles when nothing is generated). */
 int ccgp_last_sweep_plan(ccgp_handle* h, int* out_generating_columns, int* out_cov_tiles);
+/* With CCGP_OPT_SCHED_POLICY bit 2 set, the scheduled sweep keeps a time account per workgroup (8 words each, ticks of 10 ns:
+ * waiting for a task, in diagonal / update / panel-solve tiles, applying arrivals; then tasks run, XCD served, 1 if second on
+ * its CU).  Copies the account of the LAST scheduled sweep (synchronises the stream). */
+int ccgp_last_sched_profile(ccgp_handle* h, unsigned long long* out, int max_workgroups, int* out_workgroups);
 
 #ifdef __cplusplus
 }

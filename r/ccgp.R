@@ -28,6 +28,9 @@ dyn.load(Sys.getenv("CCGP_R_SHIM", "ccgpR.so"))
 if (!exists("ccgp.script")) ccgp.script <- "HX"
 if (!exists("ccgp.slim.frame")) ccgp.slim.frame <- TRUE
 if (!exists("ccgp.adv.as.written")) ccgp.adv.as.written <- FALSE
+# ADV as written goes through the literal per-draw predict.post, which reads R.Inv and the factors from every frame row:
+# a slim frame (7 numbers per row) would make every prediction NA, so that option implies the full frame
+if (ccgp.script == "ADV" && ccgp.adv.as.written) ccgp.slim.frame <- FALSE
 # how a draw's leading frame columns map to the parameter row (r/ccgp_shim.c: LAYOUT_*)
 .ccgp.layout <- switch(ccgp.script, ANI = 2L, D1 = 3L, D1F = 4L, 0L)
 .ccgp.layout.written <- if (ccgp.script == "ADV") 1L else .ccgp.layout       # predict.post as the script writes it
@@ -129,6 +132,25 @@ predict.post <- function(x.new, D.train, pars, sigma2, nu = 0) {
 .ccgp.bind <- function(f, ...) as.list(match.call(f, as.call(c(list(as.name("f")), list(...)))))[-1]
 .ccgp.nu <- function(a) if (is.null(a$nu)) 0 else as.double(a$nu)
 
+# the frame carries the y.train it was built from: prediction() outside compare.GP refactorises a slim frame against THAT
+# vector, not against whatever fit ran last in this session
+if (exists("factors.frame") && !exists(".ccgp.ref.factors.frame")) .ccgp.ref.factors.frame <- factors.frame
+if (exists(".ccgp.ref.factors.frame")) {
+  factors.frame <- function(...) {
+    out <- .ccgp.ref.factors.frame(...)
+    attr(out, "ccgp.y.train") <- get("y.train", envir = .ccgp.env)      # factors() put it there, row by row
+    out
+  }
+}
+.ccgp.frame.y <- function(frame, n) {
+  y <- attr(frame, "ccgp.y.train")
+  if (is.null(y) && exists("y.train", envir = .ccgp.env)) {
+    y <- get("y.train", envir = .ccgp.env)
+    warning("ccgp: the frame does not carry its y.train (built before source(\"r/ccgp.R\")?); using the last fit's")
+  }
+  if (is.null(y) || length(y) != n) NULL else y
+}
+
 if (exists("compare.GP") && !exists(".ccgp.ref.compare.GP")) .ccgp.ref.compare.GP <- compare.GP
 if (exists("prediction") && !exists(".ccgp.ref.prediction")) .ccgp.ref.prediction <- prediction
 
@@ -155,12 +177,11 @@ if (exists(".ccgp.ref.prediction")) {
     a <- .ccgp.bind(.ccgp.ref.prediction, ...)
     S <- nrow(a$pars.frame)
     tab <- .Call("ccgp_R_table_lookup", as.double(a$x.new), S)
-    if (is.null(tab) && !(ccgp.script == "ADV" && ccgp.adv.as.written) &&
-        ncol(a$pars.frame) < nrow(a$D.train)^2 && exists("y.train", envir = .ccgp.env) &&
-        length(get("y.train", envir = .ccgp.env)) == nrow(a$D.train)) {
+    yt <- if (is.null(tab) && ncol(a$pars.frame) < nrow(a$D.train)^2) .ccgp.frame.y(a$pars.frame, nrow(a$D.train)) else NULL
+    if (is.null(tab) && !(ccgp.script == "ADV" && ccgp.adv.as.written) && !is.null(yt)) {
       # outside compare.GP with a slim frame: the table of this one site
       r <- .Call("ccgp_R_prediction_table", a$pars.frame, .ccgp.mat(a$D.train), matrix(as.double(a$x.new), nrow = 1),
-                 as.double(a$sigma2), get("y.train", envir = .ccgp.env), .ccgp.layout, .ccgp.nu(a))
+                 as.double(a$sigma2), as.double(yt), .ccgp.layout, .ccgp.nu(a))
       tab <- rbind(as.vector(r[[1]]), as.vector(r[[2]]))
     }
     if (is.null(tab)) return(.ccgp.ref.prediction(...))          # full frame, unknown site: the literal path

@@ -9,6 +9,9 @@ import ccgp_amd  # noqa
 from ccgp_amd import api
 
 
+VARIANTS = [(0, 11), (1, 11), (2, 11), (1, 3), (1, 9), (2, 0)]
+
+
 def draws(B, K, d, rng):
     P = np.empty((B, K + K * d))
     for b in range(B):
@@ -29,8 +32,11 @@ def main():
         P = draws(B, K, d, rng)
         Xt = rng.uniform(size=(max(m, 1), d))
         res = {}
-        for sched in (0, 1, 2):
-            h.set_option(api.OPT_SCHED, sched)
+        # (sched, policy): policy 11 = default (backlog rule + XCD-local synchronisation + chaining); 3 = no chaining;
+        # 9 = agent-scope fences and stealing, chaining; 0 = agent-scope, no backlog rule, no chaining
+        for sched in VARIANTS:
+            h.set_option(api.OPT_SCHED, sched[0])
+            h.set_option(api.OPT_SCHED_POLICY, sched[1])
             t0 = time.perf_counter()
             ll, beta, st = h.loglik_batch(X, y, K, P, 1.0)
             out = [ll, beta, st]
@@ -39,10 +45,10 @@ def main():
             if n <= 1000:
                 out += list(h.loglik_grad_batch(X, y, K, P[:5], 1.0))
             res[sched] = out
-            print("n=%d B=%d m=%d sched=%d: %.1f ms  ll[0]=%.12g bad=%d" % (n, B, m, sched, 1e3 * (time.perf_counter() - t0), ll[0], int((st != 0).sum())), flush=True)
-        for sched in (1, 2):
-            same = all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) for a, b in zip(res[0], res[sched]))
-            print("   sched=%d bit-identical to launches: %s" % (sched, same), flush=True)
+            print("n=%d B=%d m=%d sched=%s: %.1f ms  ll[0]=%.12g bad=%d" % (n, B, m, sched, 1e3 * (time.perf_counter() - t0), ll[0], int((st != 0).sum())), flush=True)
+        for sched in VARIANTS[1:]:
+            same = all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) for a, b in zip(res[VARIANTS[0]], res[sched]))
+            print("   sched=%s bit-identical to launches: %s" % (sched, same), flush=True)
             ok = ok and same
     h.close()
     print("ALL OK" if ok else "MISMATCH")

@@ -135,6 +135,27 @@ def test_rinv_helpers_and_literal_predict_post(handle):
         assert got[0, 1] == pytest.approx(want[1], rel=1e-8, abs=1e-10 * s2)
 
 
+def test_rinv_helpers_take_an_asymmetric_inverse_as_the_reference_does(handle):
+    """R's solve() output is symmetric only up to rounding and the helpers accept ANY caller-supplied R.Inv:
+    var.factor1 = apply(R.Inv, 2, sum) are column sums (HX:609), beta.MLE's numerator is (1' R.Inv) y (HX:387),
+    mean.factor = R.Inv %*% (y - beta) row products (HX:608).  A visibly asymmetric matrix tells the two apart."""
+    from ccgp_amd.rsurface import CombinedGP
+    gp = CombinedGP("HX", handle=handle)
+    rng = np.random.default_rng(77)
+    for n in (7, 64, 90, 200):
+        A = rng.normal(size=(n, n)) + n * np.eye(n)          # nothing symmetric about it
+        y = rng.normal(size=n)
+        beta = orc.beta_mle(A, y)
+        assert abs(beta - float((A.sum(axis=1) @ y) / A.sum())) > 1e-6 * abs(beta)    # row sums WOULD differ
+        assert gp.beta_MLE(A, y) == pytest.approx(beta, rel=1e-11)
+        assert gp.sigma2_MLE(A, y, beta) == pytest.approx(orc.sigma2_mle(A, y, beta), rel=1e-10)
+        mf, v1, v2 = orc.factors(A, beta, y)
+        f = gp.factors(np.concatenate([A.ravel(order="F"), [beta]]), n, y)
+        np.testing.assert_allclose(f[:n], mf, rtol=1e-11, atol=1e-12 * np.abs(mf).max())
+        np.testing.assert_allclose(f[n:2 * n], v1, rtol=1e-12)
+        assert f[2 * n] == pytest.approx(v2, rel=1e-12)
+
+
 # ------------------------------------------------------------------------------- a8 / a12, small path
 @pytest.mark.parametrize("mode", [0, 1])
 def test_loglik_batch_qian_vs_oracle(handle, mode):

@@ -173,31 +173,37 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core, one_core_evals):
+def cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core, one_core_evals, in_process_all=True):
     """SURVEY 8(d)'s CPU baseline: the compiled evaluator of oracle/cpu_baseline (covariance build, LAPACK dpotrf,
     two dtrsv, log-likelihood: the same algorithmic work as the GPU path), OpenMP over evaluations with one
-    evaluation per core, on every core of this host and on one core.  Bounded sample of the workload's draws."""
+    evaluation per core, on every core of this host and on one core.  Bounded sample of the workload's draws.
+    in_process_all=False (large n): only the one-core figure; the all-cores figure then comes from cpu_process_sweep."""
     from oracle.cpu_baseline import loader as cpu
     cores = cpu.max_threads()
-    B = min(P.shape[0], per_core * cores)
-    # warm-up: the first second of a fresh OpenMP team runs several times slower (thread start, core wake-up)
-    t0 = time.perf_counter()
-    cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
-    if time.perf_counter() - t0 < 1.0:
-        while time.perf_counter() - t0 < 1.0:
-            cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
-    t0 = time.perf_counter()
-    cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
-    t_all = time.perf_counter() - t0
+    B, t_all = 0, float("nan")
+    if in_process_all:
+        B = min(P.shape[0], per_core * cores)
+        # warm-up: the first second of a fresh OpenMP team runs several times slower (thread start, core wake-up)
+        t0 = time.perf_counter()
+        cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
+        if time.perf_counter() - t0 < 1.0:
+            while time.perf_counter() - t0 < 1.0:
+                cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
+        t0 = time.perf_counter()
+        cpu.loglik_batch(X, y, K, P[:B], sigma2, mode, tau2, threads=cores)
+        t_all = time.perf_counter() - t0
     b1 = min(P.shape[0], one_core_evals)
+    if not in_process_all:
+        cpu.loglik_batch(X, y, K, P[:1], sigma2, mode, tau2, threads=1)     # warm-up of the one core
     t0 = time.perf_counter()
     cpu.loglik_batch(X, y, K, P[:b1], sigma2, mode, tau2, threads=1)
     t_one = time.perf_counter() - t0
-    return {"all_cores": B / t_all, "one_core": b1 / t_one, "cores": cores, "unit": "evals/s",
-            "sample": "%d evaluations on %d cores in %.2f s, %d on one core in %.2f s" % (B, cores, t_all, b1, t_one),
+    return {"all_cores": B / t_all if in_process_all else None, "one_core": b1 / t_one, "cores": cores, "unit": "evals/s",
+            "sample": ("%d evaluations on %d cores in %.2f s, " % (B, cores, t_all) if in_process_all else "") +
+                      "%d on one core in %.2f s" % (b1, t_one),
             "lapack": ("built-in C Cholesky (n <= 128: concurrent tiny LAPACK calls serialise inside OpenBLAS)"
                        if X.shape[0] <= 128 else
-                       "scipy OpenBLAS dpotrf/dtrsv, single-threaded per evaluation" if cpu.lapack_bound()
+                       "scipy OpenBLAS dpotrf/dtrsv" if cpu.lapack_bound()
                        else "built-in C Cholesky (no LAPACK found)")}
 
 
@@ -268,22 +274,37 @@ def cpu_predict_sample(sets, P5, draws_per_core=8):
 
 
 def cpu_logpost_latency(X, y, sigma2, calls=200):
-    """The oracle's logpost (the reference's operation sequence in numpy: solve(R) + beta.MLE + dmnorm) on the Qian
-    set, one call at a time: an emulation of what one R-level logpost costs, not a measurement of R."""
+    """What ONE sequential logpost costs on one CPU core, two ways: the oracle (the reference's operation sequence in numpy:
+    solve(R) + beta.MLE + dmnorm -- an emulation of an R-level call, not a measurement of R) and the compiled evaluator
+    (covariance + Cholesky + two solves, one evaluation per call through ctypes).  For Metro's sequential caller the device
+    call is SLOWER than the compiled CPU call: a single n = 64 evaluation is a latency problem; batching is the remedy."""
     from oracle import ccgp_oracle as orc
+    from oracle.cpu_baseline import loader as cpu
     theta_t = [math.log(0.3), math.log(15.0), math.log(4.0)]
     orc.logpost(X, theta_t, y, sigma2, "HX", (7, 3, 3, 28))
     t0 = time.perf_counter()
     for _ in range(calls):
         orc.logpost(X, theta_t, y, sigma2, "HX", (7, 3, 3, 28))
     el = (time.perf_counter() - t0) / calls
-    return {"us_per_call": 1e6 * el, "unit": "us per oracle.logpost call (numpy, reference operation sequence)", "calls": calls}
+    d = X.shape[1]
+    row = np.concatenate([[0.8, 0.2], np.full(d, 0.3), np.full(d, 15.0)])[None, :]
+    cpu.loglik_batch(X, y, 2, row, sigma2, 0, 0.0, threads=1)
+    t0 = time.perf_counter()
+    for _ in range(10 * calls):
+        cpu.loglik_batch(X, y, 2, row, sigma2, 0, 0.0, threads=1)
+    el_c = (time.perf_counter() - t0) / (10 * calls)
+    return {"us_per_call": 1e6 * el, "unit": "us per oracle.logpost call (numpy, reference operation sequence)", "calls": calls,
+            "compiled_us_per_call": 1e6 * el_c,
+            "compiled_what": "oracle/cpu_baseline evaluator, ONE evaluation per call on one core (value + beta, no R.Inv; "
+                             "ctypes binding included, as for the device figure)"}
 
 
 def cpu_predict_post_latency(X, y, x_new, sigma2, calls=200):
     """One literal predict.post call on the CPU with the cached terms given (HX:655-673: r = Mixed.corr.vec, then the
-    arithmetic with the frame row's R.Inv): the oracle's numpy restatement, one call at a time as `apply` makes them."""
+    arithmetic with the frame row's R.Inv): the oracle's numpy restatement, one call at a time as `apply` makes them, and
+    the same arithmetic compiled (oracle/cpu_baseline: ccgp_cpu_predict_post) on one core."""
     from oracle import ccgp_oracle as orc
+    from oracle.cpu_baseline import loader as cpu
     n, d = X.shape
     R = orc.mixed_corr_matrix_iso(X, 0.7, 0.3, 15.0)
     R_inv = orc.solve_inverse(R)
@@ -292,20 +313,88 @@ def cpu_predict_post_latency(X, y, x_new, sigma2, calls=200):
     t0 = time.perf_counter()
     for _ in range(calls):
         r = orc.mixed_corr_vec_iso(x_new, X, 0.7, 0.3, 15.0)
-        orc.predict_post_from_factors(r, beta, mf, v1, v2, R_inv, sigma2)
-    return {"us_per_call": 1e6 * (time.perf_counter() - t0) / calls, "cores": 1, "calls": calls,
-            "what": "numpy restatement of one R-level predict.post call (oracle/ccgp_oracle.py), cached terms given"}
+        want = orc.predict_post_from_factors(r, beta, mf, v1, v2, R_inv, sigma2)
+    el = (time.perf_counter() - t0) / calls
+    pp = cpu.PredictPost(X, 2, np.concatenate([[0.7, 0.3], np.full(d, 0.3), np.full(d, 15.0)]), beta, mf, v1, v2, R_inv, sigma2)
+    got = pp(x_new).copy()
+    t0 = time.perf_counter()
+    for _ in range(20 * calls):
+        pp(x_new)
+    el_c = (time.perf_counter() - t0) / (20 * calls)
+    return {"us_per_call": 1e6 * el, "cores": 1, "calls": calls,
+            "what": "numpy restatement of one R-level predict.post call (oracle/ccgp_oracle.py), cached terms given",
+            "compiled_us_per_call": 1e6 * el_c,
+            "compiled_what": "the same call compiled (ccgp_cpu_predict_post, one core, ctypes binding included)",
+            "compiled_matches_numpy": bool(np.allclose(got, np.ravel(want), rtol=1e-9, atol=1e-12))}
+
+
+def cpu_process_sweep(X, y, P, K, sigma2, mode, tau2, evals_per_worker=2, budget_s=60.0):
+    """All-cores figure for LARGE n as a sweep over (concurrent evaluations c) x (threads per evaluation t), c t = the host's
+    hardware threads: c worker processes (oracle/cpu_baseline/cpu_worker.py), each evaluating one draw at a time with t
+    threads (OpenMP over the covariance columns, OpenBLAS dpotrf / dtrsv with t threads).  Processes, because scipy's
+    pthread OpenBLAS serialises multi-threaded calls coming from several threads of one process; 128 single-threaded
+    dpotrf of 134 MB matrices side by side are memory-bound (round 4 measured 6 % parallel efficiency that way).
+    Wall time from "go" to the last worker's "done"; workers load and warm up before."""
+    import subprocess
+    import tempfile
+    H = os.cpu_count() or 1
+    ts = [t for t in (1, 2, 4, 8, 16, 32, 64) if t <= H and H // t >= 1]
+    if H >= 128:
+        ts = [t for t in ts if t >= 1]       # OpenBLAS builds cap at 64 threads per call
+    worker = os.path.join(ROOT, "oracle", "cpu_baseline", "cpu_worker.py")
+    rows, t_start = [], time.perf_counter()
+    with tempfile.TemporaryDirectory() as td:
+        npz = os.path.join(td, "in.npz")
+        np.savez(npz, X=X, y=y, P=P[:max(2 * H, 8)], K=K, sigma2=sigma2, mode=mode, tau2=tau2)
+        for t in ts:
+            c = max(H // t, 1)
+            if time.perf_counter() - t_start > budget_s:
+                break
+            procs = [subprocess.Popen([sys.executable, worker, npz, str(i * evals_per_worker), str(evals_per_worker), str(t)],
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                     for i in range(c)]
+            ok = all(p.stdout.readline().strip() == "ready" for p in procs)
+            t0 = time.perf_counter()
+            for p in procs:
+                try:
+                    p.stdin.write("go\n")
+                    p.stdin.flush()
+                except Exception:
+                    ok = False
+            outs = [p.stdout.readline().split() for p in procs]
+            wall = time.perf_counter() - t0
+            for p in procs:
+                p.wait()
+            ok = ok and all(len(o) == 3 and o[0] == "done" for o in outs)
+            if ok:
+                rows.append({"concurrent": c, "threads_each": t, "evals": c * evals_per_worker, "seconds": wall,
+                             "evals_per_s": c * evals_per_worker / wall})
+    return rows
 
 
 def cpu_baseline(workload, X, y, P, K, sigma2, mode, tau2):
     big = X.shape[0] > 1000
-    c = cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core=2 if big else 2000, one_core_evals=2 if big else 4000)
+    c = cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core=2 if big else 2000, one_core_evals=2 if big else 4000,
+                            in_process_all=not big)
     ref = cpu_reference_opcount(workload, X, y, P, K, sigma2, mode, tau2)
-    return {"value": c["all_cores"], "unit": "evals/s", "cores": c["cores"], "kind": "port",
-            "sample": "%s workload (n=%d): %s" % (workload, X.shape[0], c["sample"]),
-            "all_cores": c["all_cores"], "one_core": c["one_core"], "model": cpu_model(), "lapack": c["lapack"],
-            "what": "compiled evaluator oracle/cpu_baseline (covariance build + dpotrf + 2 dtrsv per evaluation, OpenMP "
-                    "over evaluations, one evaluation per core)",
+    sweep = []
+    if big:
+        # large n: the host's threads split between concurrent evaluations and threads per evaluation, best split reported
+        sweep = cpu_process_sweep(X, y, P, K, sigma2, mode, tau2)
+        best = dict(max(sweep, key=lambda r: r["evals_per_s"]), how="worker processes") if sweep else \
+            {"concurrent": 1, "threads_each": 1, "evals_per_s": c["one_core"], "how": "one core (the sweep produced nothing)"}
+    else:
+        best = {"concurrent": c["cores"], "threads_each": 1, "evals_per_s": c["all_cores"], "how": "OpenMP threads of one process"}
+    return {"value": best["evals_per_s"], "unit": "evals/s", "cores": c["cores"], "kind": "port",
+            "sample": "%s workload (n=%d): all cores = %d concurrent evaluations x %d threads each (%s)%s; %s" % (
+                workload, X.shape[0], best["concurrent"], best["threads_each"], best["how"],
+                ", best of the sweep " + ", ".join("%dx%d: %.1f/s" % (r["concurrent"], r["threads_each"], r["evals_per_s"]) for r in sweep) if sweep else "",
+                c["sample"]),
+            "all_cores": best["evals_per_s"], "all_cores_config": best, "sweep": sweep, "one_core": c["one_core"],
+            "parallel_efficiency": best["evals_per_s"] / (c["one_core"] * c["cores"]) if c["one_core"] > 0 else None,
+            "model": cpu_model(), "lapack": c["lapack"],
+            "what": "compiled evaluator oracle/cpu_baseline (covariance build + dpotrf + 2 dtrsv per evaluation); all_cores = the "
+                    "best split of the host's hardware threads between concurrent evaluations and threads per evaluation",
             "reference_opcount": ref}
 
 

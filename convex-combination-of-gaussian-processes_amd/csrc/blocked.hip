@@ -1390,7 +1390,15 @@ __device__ inline unsigned long long sched_finish(const SchedArgs& a, const sche
   unsigned long long* slots = a.slots + (size_t)ctl[3];
   unsigned long long next = 0;
   auto add = [&](int idx, int inc) { return __hip_atomic_fetch_add(c + idx, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto raise = [&](int idx, int level) {   // hi = max(hi, level) in one atomic step; the word it replaced (or met)
+    int old = __hip_atomic_load(c + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (sched::hi16(old) < level &&
+           !__hip_atomic_compare_exchange_strong(c + idx, &old, (level << 16) | sched::lo16(old), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {}
+    return old;
+  };
   auto emit = [&](int k2, int j2, int i2) {
+    if ((a.policy & 16) && b == 0 && k2 == sched::kT && j2 == 1) return;   // test hook: lose matrix 0's block column 1 (the abort path)
     if (chain && lane == 0 && next == 0) {
       next = sched::encode(k2, j2, i2, b);
       return;
@@ -1398,8 +1406,11 @@ __device__ inline unsigned long long sched_finish(const SchedArgs& a, const sche
     const int pos = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(slots + pos, sched::encode(k2, j2, i2, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  const bool pivot = kind == sched::kT && i == j + 1 && j + 1 < s.nt;
+  const bool pivot = sched::is_pivot_solve(s, kind, j, i);
   if (kind == sched::kD || pivot) {
+    // one lane per row, 64 rows per pass: the row's update, the fence, its announcement (sched_logic.h: row_after_D /
+    // row_after_pivot; the level a row announces is the one IT was waiting for, which a fan-out that overtook another may
+    // find below its own)
     if (pivot) {                                          // D(j+1) first: it is the longest task that follows
       bool rd = false;
       if (lane == 0) rd = sched::lo16(add(2 * R, 1 << 16)) >= j + 1;
@@ -1409,15 +1420,15 @@ __device__ inline unsigned long long sched_finish(const SchedArgs& a, const sche
     const int r0 = kind == sched::kD ? j + 1 : j + 2;
     for (int rb = r0; rb < R; rb += 64) {                 // wave-uniform trip count: the fence below is executed by every lane
       const int r = rb + lane;
-      bool rd = false;
-      if (r < R) rd = kind == sched::kD ? sched::row_after_D(s, j, r, add) : sched::row_after_pivot(s, j, r, add);
+      int jn = -1;
+      if (r < R) jn = kind == sched::kD ? sched::row_after_D(s, j, r, raise) : sched::row_after_pivot(s, j, r, raise);
       sched_acq_rel(xcd);
-      if (rd) emit(kind == sched::kD ? sched::kT : sched::kU, kind == sched::kD ? j : j + 1, r);
+      if (jn >= 0) emit(kind == sched::kD ? sched::kT : sched::kU, jn, r);
     }
   } else if (lane == 0) {
     // one arrival, at most one announcement: the shared single-thread rule, with the fence between the two
     int ak = 0, aj = 0, ai = 0;
-    sched::finish(s, kind, j, i, add, [&](int k2, int j2, int i2) { ak = k2; aj = j2; ai = i2; });
+    sched::finish_single(s, kind, j, i, add, [&](int k2, int j2, int i2) { ak = k2; aj = j2; ai = i2; });
     sched_acq_rel(xcd);
     if (ak) emit(ak, aj, ai);
   }

@@ -603,7 +603,7 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
     h->opt_sched = value;
     return CCGP_OK;
   }
-  if (option == CCGP_OPT_SCHED_POLICY && value >= 0 && value <= 15) {
+  if (option == CCGP_OPT_SCHED_POLICY && value >= 0 && value <= 31) {
     h->opt_sched_policy = value;
     return CCGP_OK;
   }

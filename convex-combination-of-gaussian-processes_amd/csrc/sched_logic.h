@@ -12,10 +12,17 @@
 //   D(j+1)   <- T(j+1, j), T(nt, j)
 //   U(i,j+1) <- T(i, j),   T(j+1, j)
 //   T(i,j)   <- U(i, j) (j >= 1, i != nt),  D(j)
-// Per row three monotone 16 + 16-bit counters in one int each; the arrival that lifts min(lo, hi) announces the task:
-//   cu[i] : lo = T(i, .) finished ("own"),          hi = pivot-row solves T(j+1, j) finished   -> U(i, min)
-//   ct[i] : lo = 1 + U(i, .) finished,              hi = D(.) finished that concern row i       -> T(i, min - 1)
-//   cd    : lo = thin-row solves T(nt, .) finished, hi = pivot-row solves finished              -> D(min)
+// Per row two words of 16 + 16 bits, per matrix one more; the ONE atomic update after which both halves admit the row's
+// next task announces it:
+//   cu[i] : lo = T(i, .) finished ("own"),  hi = highest pivot-row solve T(L, L-1) seen (a MAXIMUM, not a count) -> U(i, lo)
+//   ct[i] : lo = 1 + U(i, .) finished,      hi = 1 + highest D(.) seen (a maximum)                               -> T(i, lo - 1)
+//   cd    : lo = thin-row solves T(nt, .) finished, hi = pivot-row solves finished (both counts: strictly sequential) -> D(min)
+// Why maxima: the fan-out of a diagonal block or of a pivot-row solve visits its rows one after the other, and a row that
+// has received its arrival can start tasks that lead to the NEXT block column's fan-out while this one is still under way
+// (own-progress arrivals announce too), so a row may see block column L + 1 before L.  "L + 1 seen" implies that block
+// column L's tile is finished (L + 1 could not exist otherwise), so the maximum is the right readiness test, and a late
+// arrival that changes nothing announces nothing.  (A count in that field announced tasks twice when a host thread was
+// descheduled in the middle of a fan-out: tests/test_sched_logic.py runs the rules from eight threads with random sleeps.)
 // Announced tasks go to a FIFO of the matrix's queue (one queue per XCD: matrix b lives on queue b % 8, so all tiles of a
 // matrix share one L2); a workgroup takes the next slot index and waits until that slot is filled.  A workgroup never waits
 // for a particular task, only for "one more announcement", so any number of resident workgroups makes progress.
@@ -80,58 +87,75 @@ CCGP_HD inline void init_counters(const Shape& s, int* c) {
   for (int i = 0; i < R; ++i) {
     const int f = first_col(s, i);
     c[i] = f;                                            // cu: own = f (as if T(i, 0 .. f-1) were done), pivot = 0
-    // ct: lo = 1 + U done; a row whose first task is T(i, f) behaves as if U(i, 1 .. f) were done.  Thin row: never waits for U.
-    c[R + i] = (i == s.nt ? 0x7fff : f + 1) | (f << 16);   // hi = f: as if D(0 .. f-1) had arrived
+    // ct: lo = 1 + U done; a row whose first task is T(i, f) behaves as if U(i, 1 .. f) were done
+    c[R + i] = (f + 1) | (f << 16);                      // hi = f: as if D(0 .. f-1) had been seen (the thin row's word is unused)
   }
   c[2 * R] = 0;
 }
 
-// Arrivals of a finished task.  `add(counter index, increment)` performs an atomic fetch-add on the matrix's counter and
-// returns the OLD value; `announce(kind, j, i)` queues a task of the same matrix.  Both are called from one thread here; the
-// device kernel runs the D and pivot-row fan-outs with one lane per row (sched_finish_parallel in blocked.hip uses the same
-// row rules: row_after_D / row_after_pivot).
+// Arrivals of a finished task.  The caller supplies three primitives on the matrix's counters (index into the
+// counters_per_matrix words), each ONE atomic read-modify-write that returns the OLD word:
+//   add(idx, inc)      fetch-add
+//   raise(idx, level)  hi = max(hi, level), lo untouched (compare-exchange loop; returns the word it saw when hi >= level already)
+// and `announce(kind, j, i)`, which queues a task of the same matrix.  The device kernel runs the two fan-outs with one lane
+// per row (sched_finish in blocked.hip) on the same row rules.
 CCGP_HD inline int lo16(int v) { return v & 0xffff; }
 CCGP_HD inline int hi16(int v) { return (v >> 16) & 0xffff; }
+// did raising hi to `level` carry it over lo (the row's waiting task became ready through THIS update)?
+CCGP_HD inline bool crossed(int old, int level) { return hi16(old) < lo16(old) && lo16(old) <= level; }
 
-// D(j) finished: row i gets hi(ct[i]) += 1.  Returns true when T(i, j) is thereby ready.
-template <class Add>
-CCGP_HD inline bool row_after_D(const Shape& s, int j, int i, Add add) {
-  if (!has_T(s, i, j)) return false;
-  const int old = add(rows(s) + i, 1 << 16);
-  return lo16(old) >= j + 1;                             // hi is now j + 1 by construction
+// D(j) finished.  Row i: returns the block column of the solve T(i, .) this made ready, or -1.
+template <class Raise>
+CCGP_HD inline int row_after_D(const Shape& s, int j, int i, Raise raise) {
+  if (!has_T(s, i, j)) return -1;
+  if (i == s.nt) return j;                               // the thin row waits for nothing else: no counter
+  const int old = raise(rows(s) + i, j + 1);
+  return crossed(old, j + 1) ? lo16(old) - 1 : -1;
 }
-// pivot-row solve T(j+1, j) finished: row i gets hi(cu[i]) += 1.  Returns true when U(i, j+1) is thereby ready.
-template <class Add>
-CCGP_HD inline bool row_after_pivot(const Shape& s, int j, int i, Add add) {
-  if (i == s.nt || (i < s.nt && i <= j + 1)) return false;   // finished rows, the pivot row itself, the thin row: no U(i, j+1)
-  const int old = add(i, 1 << 16);
-  return has_U(s, i, j + 1) && lo16(old) >= j + 1;
+// pivot-row solve T(j+1, j) finished.  Row i: returns the block column of the update U(i, .) this made ready, or -1.
+template <class Raise>
+CCGP_HD inline int row_after_pivot(const Shape& s, int j, int i, Raise raise) {
+  if (i == s.nt || (i < s.nt && i <= j + 1)) return -1;   // finished rows, the pivot row itself, the thin row: no U(i, j+1)
+  const int old = raise(i, j + 1);
+  return (crossed(old, j + 1) && has_U(s, i, lo16(old))) ? lo16(old) : -1;
 }
 
+// the tasks with ONE arrival and at most one announcement: U(i, j), and T(i, j) of the thin row or of an ordinary row
 template <class Add, class Announce>
-CCGP_HD inline void finish(const Shape& s, int kind, int j, int i, Add add, Announce announce) {
+CCGP_HD inline void finish_single(const Shape& s, int kind, int j, int i, Add add, Announce announce) {
   const int R = rows(s);
-  if (kind == kD) {
-    for (int r = j + 1; r < R; ++r)
-      if (row_after_D(s, j, r, add)) announce((int)kT, j, r);
-  } else if (kind == kU) {
+  if (kind == kU) {
     const int old = add(R + i, 1);                       // lo(ct[i]) -> j + 1
     if (hi16(old) >= j + 1) announce((int)kT, j, i);
-  } else {   // kT
-    if (j + 1 >= s.nt) return;                           // last block column: nothing follows
+  } else if (kind == kT && j + 1 < s.nt) {               // (last block column: nothing follows)
     if (i == s.nt) {                                     // thin row -> D(j+1) once the pivot-row solve is in as well
       const int old = add(2 * R, 1);
       if (hi16(old) >= j + 1) announce((int)kD, j + 1, j + 1);
-    } else if (i == j + 1) {                             // pivot row of the next block column
-      const int old = add(2 * R, 1 << 16);
-      if (lo16(old) >= j + 1) announce((int)kD, j + 1, j + 1);
-      for (int r = j + 2; r < R; ++r)
-        if (row_after_pivot(s, j, r, add)) announce((int)kU, j + 1, r);
     } else {                                             // an ordinary row: its own progress
       const int old = add(i, 1);                         // lo(cu[i]) -> j + 1
       if (has_U(s, i, j + 1) && hi16(old) >= j + 1) announce((int)kU, j + 1, i);
-      // a row without U(i, j+1) (identity row te = j + 1 ... cannot happen: has_T(i, j) implies j >= te)
     }
+  }
+}
+CCGP_HD inline bool is_pivot_solve(const Shape& s, int kind, int j, int i) { return kind == kT && i == j + 1 && j + 1 < s.nt; }
+
+template <class Add, class Raise, class Announce>
+CCGP_HD inline void finish(const Shape& s, int kind, int j, int i, Add add, Raise raise, Announce announce) {
+  const int R = rows(s);
+  if (kind == kD) {
+    for (int r = j + 1; r < R; ++r) {
+      const int jt = row_after_D(s, j, r, raise);
+      if (jt >= 0) announce((int)kT, jt, r);
+    }
+  } else if (is_pivot_solve(s, kind, j, i)) {            // pivot row of the next block column
+    const int old = add(2 * R, 1 << 16);
+    if (lo16(old) >= j + 1) announce((int)kD, j + 1, j + 1);
+    for (int r = j + 2; r < R; ++r) {
+      const int ju = row_after_pivot(s, j, r, raise);
+      if (ju >= 0) announce((int)kU, ju, r);
+    }
+  } else {
+    finish_single(s, kind, j, i, add, announce);
   }
 }
 

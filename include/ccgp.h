@@ -121,7 +121,9 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           invalidate + store completion); 0 = agent-scope release / acquire fences, which write back and
  *                           invalidate that L2 per tile (same bits, 40 % slower: DESIGN.md K3); bit 2: keep the per-workgroup
  *                           time account that ccgp_last_sched_profile reads; bit 3: a workgroup goes on with the first task its
- *                           own arrivals made ready instead of queueing it */
+ *                           own arrivals made ready instead of queueing it; bit 4 (tests only): drop the announcements of
+ *                           matrix 0's second block column, so that the sweep cannot finish -- it must then abort after
+ *                           CCGP_SCHED_TIMEOUT_MS (environment, default 30000) and fail every evaluation of the chunk, not hang */
 enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3,
        CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5, CCGP_OPT_FUSED_COV = 6, CCGP_OPT_SCHED = 7,
        CCGP_OPT_SCHED_POLICY = 8 };

@@ -138,8 +138,16 @@ static void fwd(const double* L, int n, double* x) {
 }
 
 /* lower triangle of scale * R_mixed + shift; xt = X scaled per component: xt[c][k][i] = theta_ck x_ik */
+static void build_cov_inner(const double* X, int n, int d, int K, const double* row, int ldp, double scale, double shift,
+                            double* A, double* u, double* xt, int inner);
 static void build_cov(const double* X, int n, int d, int K, const double* row, int ldp, double scale, double shift,
                       double* A, double* u, double* xt) {
+  build_cov_inner(X, n, d, K, row, ldp, scale, shift, A, u, xt, 1);
+}
+/* inner > 1: the columns of ONE matrix are shared among `inner` OpenMP threads (an evaluation that has several cores to
+ * itself: the concurrency x BLAS-threads sweep of bench.py); the scratch row then lives per thread */
+static void build_cov_inner(const double* X, int n, int d, int K, const double* row, int ldp, double scale, double shift,
+                            double* A, double* u, double* xt, int inner) {
   double sw = 0.0;
   for (int c = 0; c < K; ++c) sw += row[(size_t)c * ldp] * row[(size_t)c * ldp];
   for (int c = 0; c < K; ++c)
@@ -153,7 +161,10 @@ static void build_cov(const double* X, int n, int d, int K, const double* row, i
       u[(size_t)c * n + i] = s;
     }
   const double f = scale / sw;
-  double* tmp = xt + (size_t)K * d * n;   /* n doubles of scratch behind the scaled coordinates */
+#pragma omp parallel num_threads(inner) if (inner > 1)
+  {
+  double* tmp = inner > 1 ? (double*)malloc(sizeof(double) * n) : xt + (size_t)K * d * n;   /* n doubles of scratch (behind the scaled coordinates when single-threaded) */
+#pragma omp for schedule(dynamic, 8)
   for (int j = 0; j < n; ++j) {
     double* col = A + (size_t)j * n;
     for (int i = j; i < n; ++i) col[i] = shift;
@@ -169,6 +180,8 @@ static void build_cov(const double* X, int n, int d, int K, const double* row, i
       }
       for (int i = j; i < n; ++i) col[i] += w2 * exp(tmp[i]);
     }
+  }
+  if (inner > 1) free(tmp);
   }
 }
 
@@ -297,6 +310,94 @@ int ccgp_cpu_predict_batch(const double* X, int n, int d, const double* y, int K
   }
   blas_restore(prev_blas);
   return bad;
+}
+
+/* ONE evaluation at a time with `inner` threads to itself (covariance columns shared by OpenMP, dpotrf / dtrsv with `inner`
+ * OpenBLAS threads): the building block of bench.py's (concurrent evaluations x threads per evaluation) sweep, where the
+ * concurrency comes from separate worker PROCESSES -- scipy's pthread OpenBLAS serialises multi-threaded calls that arrive
+ * from several threads of one process.  mode / outputs as ccgp_cpu_loglik_batch. */
+int ccgp_cpu_loglik_seq(const double* X, int n, int d, const double* y, int K, const double* params, int ldp, int B,
+                        double sigma2, int mode, double tau2, double* out_ll, double* out_beta, int* status, int inner) {
+  int bad = 0;
+  if (inner < 1) inner = 1;
+  const int prev = g_setthr ? g_getthr() : 0;
+  if (g_setthr) g_setthr(inner);
+  double* A = (double*)malloc(sizeof(double) * (size_t)n * n);
+  double* u = (double*)malloc(sizeof(double) * (size_t)K * n);
+  double* xt = (double*)malloc(sizeof(double) * ((size_t)K * d + 1) * n);
+  double* zy = (double*)malloc(sizeof(double) * n);
+  double* z1 = (double*)malloc(sizeof(double) * n);
+  for (int b = 0; b < B; ++b) {
+    const double* row = params + b;
+    const double cs = sigma2 * sum_w2(row, K, ldp);
+    build_cov_inner(X, n, d, K, row, ldp, mode == 1 ? cs : 1.0, mode == 1 ? tau2 : 0.0, A, u, xt, inner);
+    const int info = factor(A, n, mode == 0 ? n * 2.220446049250313e-16 : 0.0);
+    if (status) status[b] = info;
+    if (info != 0) {
+      out_ll[b] = NAN;
+      if (out_beta) out_beta[b] = NAN;
+      ++bad;
+      continue;
+    }
+    double logdet = 0.0;
+    for (int i = 0; i < n; ++i) logdet += log(A[i + (size_t)i * n]);
+    logdet *= 2.0;
+    memcpy(zy, y, sizeof(double) * n);
+    fwd(A, n, zy);
+    double ll, beta = 0.0, q = 0.0;
+    if (mode == 0) {
+      for (int i = 0; i < n; ++i) z1[i] = 1.0;
+      fwd(A, n, z1);
+      double s11 = 0.0, s1y = 0.0;
+      for (int i = 0; i < n; ++i) { s11 += z1[i] * z1[i]; s1y += z1[i] * zy[i]; }
+      beta = s1y / s11;
+      for (int i = 0; i < n; ++i) { const double v = zy[i] - beta * z1[i]; q += v * v; }
+      ll = -0.5 * (n * kLog2Pi + n * log(cs) + logdet + q / cs);
+    } else {
+      for (int i = 0; i < n; ++i) q += zy[i] * zy[i];
+      ll = -0.5 * (n * kLog2Pi + logdet + q);
+    }
+    out_ll[b] = ll;
+    if (out_beta) out_beta[b] = beta;
+  }
+  free(A); free(u); free(xt); free(zy); free(z1);
+  if (g_setthr && prev > 0) g_setthr(prev);
+  return bad;
+}
+
+/* ONE literal predict.post call with the cached terms given (HX:655-673): r = Mixed.corr.vec(x.new, D.train, ...) in the
+ * expanded form (HX:367-375, HX:425-431), mean = beta + mean.factor' r, var = sigma2 (1 - r' R.Inv r + (1 - v1' r)^2 / v2).
+ * What one R-level call costs in compiled code on one core: the sequential caller's CPU comparator in bench.py. */
+void ccgp_cpu_predict_post(const double* x, const double* X, int n, int d, int K, const double* row, double beta,
+                           const double* mean_factor, const double* v1, double v2, const double* Rinv, double sigma2,
+                           double* r, double* out) {
+  const double sw = sum_w2(row, K, 1);
+  for (int i = 0; i < n; ++i) r[i] = 0.0;
+  for (int c = 0; c < K; ++c) {
+    double ut = 0.0;
+    for (int k = 0; k < d; ++k) ut += x[k] * x[k] * row[K + c * d + k];
+    const double w2 = row[c] * row[c] / sw;
+    for (int i = 0; i < n; ++i) {
+      double sdot = 0.0, ui = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double th = row[K + c * d + k], xi = X[i + (size_t)k * n];
+        sdot += th * xi * x[k];
+        ui += th * xi * xi;
+      }
+      r[i] += w2 * exp(-((ut - 2.0 * sdot) + ui));
+    }
+  }
+  double mr = 0.0, vr = 0.0, q = 0.0;
+  for (int j = 0; j < n; ++j) {
+    const double* col = Rinv + (size_t)j * n;
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t += col[i] * r[i];
+    q += t * r[j];
+    mr += mean_factor[j] * r[j];
+    vr += v1[j] * r[j];
+  }
+  out[0] = beta + mr;
+  out[1] = sigma2 * (1.0 - q + (1.0 - vr) * (1.0 - vr) / v2);
 }
 
 int ccgp_cpu_max_threads(void) { return omp_get_max_threads(); }

@@ -7,8 +7,11 @@
 //       D(j)   : T(j, k) for k < j, T(nt, k) for k < j
 //       U(i,j) : T(i, k), T(j, k) for first_col(i) <= k < j
 //       T(i,j) : D(j), and U(i, j) where it exists.
-// usage: sched_sim nt ne lower seed threads
+// A last argument `chaos` > 0 makes a thread sleep for a few microseconds after every chaos-th counter increment on average:
+// the descheduling in the middle of a fan-out that a loaded host produces once in a hundred runs, on every run.
+// usage: sched_sim nt ne lower seed threads [chaos]
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -29,6 +32,7 @@ int main(int argc, char** argv) {
   const Shape s{std::atoi(argv[1]), std::atoi(argv[2]), std::atoi(argv[3])};
   const unsigned seed = (unsigned)std::atoi(argv[4]);
   const int nthreads = std::atoi(argv[5]);
+  const int chaos = argc > 6 ? std::atoi(argv[6]) : 0;
   const int cpm = counters_per_matrix(s);
   std::vector<int> init(cpm);
   init_counters(s, init.data());
@@ -93,12 +97,22 @@ int main(int argc, char** argv) {
         std::lock_guard<std::mutex> g(mu);
         finished.insert(Key(kind, j, i));
       }
-      auto add = [&](int idx, int inc) { return c[idx].fetch_add(inc, std::memory_order_acq_rel); };
+      auto add = [&](int idx, int inc) {
+        const int old = c[idx].fetch_add(inc, std::memory_order_acq_rel);
+        if (chaos > 0 && rng() % (unsigned)chaos == 0) std::this_thread::sleep_for(std::chrono::microseconds(20 + rng() % 200));
+        return old;
+      };
       auto ann = [&](int k2, int j2, int i2) {
         std::lock_guard<std::mutex> g(mu);
         announce_locked(k2, j2, i2);
       };
-      finish(s, kind, j, i, add, ann);
+      auto raise = [&](int idx, int level) {
+        int old = c[idx].load(std::memory_order_acquire);
+        while (hi16(old) < level && !c[idx].compare_exchange_weak(old, (level << 16) | lo16(old), std::memory_order_acq_rel)) {}
+        if (chaos > 0 && rng() % (unsigned)chaos == 0) std::this_thread::sleep_for(std::chrono::microseconds(20 + rng() % 200));
+        return old;
+      };
+      finish(s, kind, j, i, add, raise, ann);
       {
         std::lock_guard<std::mutex> g(mu);
         --running;
@@ -122,6 +136,6 @@ int main(int argc, char** argv) {
       if (has_U(s, i, j) && !announced.count(Key(kU, j, i))) { ++errors; std::fprintf(stderr, "U(%d,%d) missing\n", i, j); }
     }
   }
-  std::printf("nt=%d ne=%d lower=%d threads=%d: %ld tasks, %d errors\n", s.nt, s.ne, s.lower, nthreads, want, errors);
+  std::printf("nt=%d ne=%d lower=%d threads=%d chaos=%d: %ld tasks, %d errors\n", s.nt, s.ne, s.lower, nthreads, chaos, want, errors);
   return errors ? 1 : 0;
 }

@@ -434,13 +434,9 @@ def parse_args():
                     help="cfg4: size of the hyperparameter grid, sharded over the GPUs (BASELINE config 4: 512)")
     ap.add_argument("--evals-per-gpu", type=int, default=0,
                     help="cfg4: fixed per-GPU slice instead of a fixed grid (weak scaling; experiments only)")
-    ap.add_argument("--strips", type=int, default=0, choices=[0, 1, 2],
-                    help="pin the update kernel's column-strip count (ccgp_set_option; 0 = per-launch choice)")
     ap.add_argument("--no-tail-strips", action="store_true", help="every update tile whole (ccgp_set_option; measurements)")
     ap.add_argument("--half-tail-strips", action="store_true", help="half-width tail strips only, as in rounds 2 - 3 (ccgp_set_option; measurements)")
     ap.add_argument("--no-fuse-diag", action="store_true", help="separate diag_kernel launches (ccgp_set_option; measurements)")
-    ap.add_argument("--fused-cov", action="store_true",
-                    help="whole update tiles generate their covariance tile, cov_kernel writes the rest (ccgp_set_option; measurements)")
     ap.add_argument("--sched", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="blocked sweep: 0 = one launch per phase and block column (rounds 1 - 4); 1 = dataflow tile scheduler, two "
                          "workgroups per CU; 2 = one per CU; 3 = the library's choice by chunk size (default) (ccgp_set_option)")
@@ -601,8 +597,6 @@ def run_loglik_workload(c):
 
     h = api.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
-    if args.strips:
-        h.set_option(api.OPT_UPDATE_STRIPS, args.strips)
     if args.half_tail_strips:
         h.set_option(api.OPT_TAIL_STRIPS, 2)
     if args.no_tail_strips:
@@ -611,8 +605,6 @@ def run_loglik_workload(c):
         h.set_option(api.OPT_FUSE_DIAG, 0)
     if args.small_grid16:
         h.set_option(api.OPT_SMALL_GRID16, 1)
-    if args.fused_cov:
-        h.set_option(api.OPT_FUSED_COV, 1)
     if args.sched >= 0:
         h.set_option(api.OPT_SCHED, args.sched)
     if args.sched_policy >= 0:

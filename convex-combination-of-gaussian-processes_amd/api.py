@@ -18,7 +18,7 @@ MEAN_ZERO_PLUS_TAU2 = 1
 PRIOR_INVGAMMA, PRIOR_GV, PRIOR_ISO, PRIOR_ANI = 0, 1, 2, 3
 T_COV, T_UPDATE, T_DIAG, T_TRSM, T_SOLVE, T_FUSED = range(6)
 KERNEL_GAUSS, KERNEL_MATERN, KERNEL_MATERN_SPLINE = 0, 1, 2
-OPT_UPDATE_STRIPS, OPT_SMALL_LDS, OPT_FUSE_DIAG, OPT_TAIL_STRIPS, OPT_WIDE_OFFSETS, OPT_SMALL_GRID16, OPT_FUSED_COV = 0, 1, 2, 3, 4, 5, 6
+OPT_FUSE_DIAG, OPT_TAIL_STRIPS, OPT_WIDE_OFFSETS, OPT_SMALL_GRID16 = 2, 3, 4, 5
 OPT_SCHED, OPT_SCHED_POLICY = 7, 8
 TIMING_NAMES = ("cov", "update", "diag", "trsm", "solve", "fused", "sweep")
 
@@ -86,7 +86,6 @@ SIGNATURES = {
     "ccgp_enable_timing": (c_int, [c_void_p, c_int]),
     "ccgp_get_timing": (c_int, [c_void_p, c_int, _dp, _ip]),
     "ccgp_last_sched_profile": (c_int, [c_void_p, c_void_p, c_int, _ip]),
-    "ccgp_last_sweep_plan": (c_int, [c_void_p, _ip, _ip]),
 }
 
 _bound = None
@@ -316,7 +315,7 @@ class Handle:
         self._chk(lib().ccgp_set_workspace_limit(self._h, int(nbytes)))
 
     def set_option(self, option, value):
-        """Measurement switches of include/ccgp.h (OPT_UPDATE_STRIPS, OPT_SMALL_LDS)."""
+        """Measurement switches of include/ccgp.h (OPT_*)."""
         self._chk(lib().ccgp_set_option(self._h, int(option), int(value)))
 
     def reserve(self, n, d, K, B, m=0):
@@ -353,14 +352,6 @@ class Handle:
         out[:, :5] *= 0.01
         return out
 
-    def last_sweep_plan(self):
-        """(block columns whose update generated its covariance tiles, 64 x 64 tiles per matrix left to cov_kernel) of the
-        last blocked sweep."""
-        g, t = c_int(), c_int()
-        self._chk(lib().ccgp_last_sweep_plan(self._h, ctypes.byref(g), ctypes.byref(t)))
-        return g.value, t.value
-
-    # -- a1..a5 -------------------------------------------------------------------------
     def corr_matrix(self, X, theta):
         X = _f(X)
         n, d = X.shape

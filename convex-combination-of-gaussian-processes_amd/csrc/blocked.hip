@@ -85,15 +85,6 @@ struct GemmArgs {
   int* status;
   int n;
   double ptol;   // pivot_tolerance(mean_mode, n) for the fused diagonal factorisation
-  // round 4: whole update tiles that lie inside the matrix proper GENERATE their covariance tile instead of reading it
-  // (update_tile_il_gen); cov_kernel then writes only block column 0, the diagonal tiles, the edge row and the block
-  // columns whose launch has a tail of ring strips
-  int fuse_gen;
-  const double* xpad;     // design zero-padded to npad rows, npad x d
-  const double* upad;     // u[z][c][i], nb x K x npad (cov_u_kernel)
-  const double* params;   // draws, column-major with leading dimension ldp
-  int ldp, K, d, draw0, mean_mode;
-  double sigma2, tau2;
 };
 
 // One output tile strip, C = C - P Q' (MODE 0, update) or C = P Q' (MODE 1, trsm): 128 rows x
@@ -386,119 +377,6 @@ __device__ __forceinline__ void update_tile_il(double* smem, const double* P, in
       *(d4*)(Cl + (size_t)(16 * r + x) * ld) = o;
     }
   }
-}
-
-// LDS of the generating epilogue (doubles), laid over the k-loop's stage images once they are free:
-//   etab[256] | xs[K][d][128] (row coordinates times theta) | xc[d][128] | ur[K][128] | uc[K][128] | w2[K]
-__host__ __device__ inline size_t gen_lds_doubles(int d, int K) {
-  return (size_t)kExpTableDoubles + (size_t)K * d * kTile + (size_t)d * kTile + (size_t)2 * K * kTile + K;
-}
-
-// Whole update tile whose covariance tile is GENERATED here instead of being read: T = R_tile - acc.  Round 3's review
-// asked for it (five HBM passes over the matrix: cov write, update read + write, trsm read + write); what it costs was
-// measured first in the real kernel (profiles/r04_experiments.md section 13: a tile's worth of fp64 vector instructions
-// in this epilogue costs 6.9 ms per 512-matrix sweep, half of their issue time hides in the 8 % of SIMD time the MFMA
-// stream leaves open) against 13 ms of cov_kernel.  Same arithmetic, operand values and order as cov_kernel
-// (cov_mix_term; u from cov_u_kernel; scale and shift formed the same way), so the bits of a tile do not depend on who
-// produced it.  Lane = 4 consecutive rows x 16 columns (acc[x][y] register r = row0 + 4 l15 + y, col0 + 16 r + 4 l4 + x):
-// per column group r two 2 x 4 micro-tiles whose row and column coordinates come as ds_read_b128.
-__device__ __forceinline__ void update_tile_il_gen(double* smem, const double* P, int ldP, const double* Q, int ldQ,
-                                                   int Kdim, double* C, int ld, const GemmArgs& g, int b, int i) {
-  d4 acc[4][4];
-  tile_accumulate_il(smem, P, ldP, Q, ldQ, Kdim, acc);
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  const int d = g.d, K = g.K, tid = tid_now();
-  double* etab = smem;
-  double* xs = etab + kExpTableDoubles;      // [K][d][128]
-  double* xc = xs + (size_t)K * d * kTile;   // [d][128]
-  double* ur = xc + (size_t)d * kTile;       // [K][128]
-  double* uc = ur + (size_t)K * kTile;       // [K][128]
-  double* w2 = uc + (size_t)K * kTile;       // [K]
-  const int I0 = i * kTile, J0 = g.j * kTile, gb = g.draw0 + b;
-  __syncthreads();   // every wave has read its last fragments: the stage images are free
-  exp_table_load(etab, tid, 256);
-  for (int e = tid; e < K * d * kTile; e += 256) {
-    const int r = e & (kTile - 1), ck = e >> 7, k = ck % d;
-    xs[e] = g.xpad[I0 + r + (size_t)k * g.npad] * g.params[gb + (size_t)(K + ck) * g.ldp];
-  }
-  for (int e = tid; e < d * kTile; e += 256) xc[e] = g.xpad[J0 + (e & (kTile - 1)) + (size_t)(e >> 7) * g.npad];
-  const double* ub = g.upad + (size_t)b * K * g.npad;
-  for (int e = tid; e < K * kTile; e += 256) {
-    ur[e] = ub[(size_t)(e >> 7) * g.npad + I0 + (e & (kTile - 1))];
-    uc[e] = ub[(size_t)(e >> 7) * g.npad + J0 + (e & (kTile - 1))];
-  }
-  if (tid < K) {
-    const double w = g.params[gb + (size_t)tid * g.ldp];
-    w2[tid] = w * w;
-  }
-  __syncthreads();
-  double sw = 0.0;
-  for (int c = 0; c < K; ++c) sw += w2[c];
-  const double post_scale = g.mean_mode == 1 ? g.sigma2 * sw : 1.0;
-  const double post_shift = g.mean_mode == 1 ? g.tau2 : 0.0;
-  const double inv_sw = 1.0 / sw;
-  const double scale = post_scale * inv_sw;
-
-  const int lane = tid & 63, wave = tid >> 6;
-  const int row0 = (wave >> 1) * 64, col0 = (wave & 1) * 64;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int rl = row0 + 4 * l15;             // this lane's four rows rl .. rl + 3
-  constexpr int RY = 2;                      // rows of a micro-tile: 2 x 4 keeps sd + mix at 32 VGPRs beside the 128 of acc (4 x 4 spilled 280 B)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int cl = col0 + 16 * r + 4 * l4;   // and four columns cl .. cl + 3 of column group r
-#pragma unroll
-    for (int y0 = 0; y0 < 4; y0 += RY) {
-      double mix[RY][4];                     // [y][x]
-#pragma unroll
-      for (int y = 0; y < RY; ++y)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) mix[y][x] = 0.0;
-      for (int c = 0; c < K; ++c) {
-        double sd[RY][4];
-#pragma unroll
-        for (int y = 0; y < RY; ++y)
-#pragma unroll
-          for (int x = 0; x < 4; ++x) sd[y][x] = 0.0;
-        const double* xsc = xs + (size_t)c * d * kTile + rl + y0;
-        for (int k = 0; k < d; ++k) {
-          const d2 ra = *(const d2*)(xsc + k * kTile);
-          const d2 ca = *(const d2*)(xc + k * kTile + cl), cb = *(const d2*)(xc + k * kTile + cl + 2);
-          const double rv[2] = {ra[0], ra[1]}, cv[4] = {ca[0], ca[1], cb[0], cb[1]};
-#pragma unroll
-          for (int y = 0; y < RY; ++y)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) sd[y][x] = fma(rv[y], cv[x], sd[y][x]);
-        }
-        const d2 ua = *(const d2*)(ur + c * kTile + rl + y0);
-        const d2 va = *(const d2*)(uc + c * kTile + cl), vb = *(const d2*)(uc + c * kTile + cl + 2);
-        const double uv[2] = {ua[0], ua[1]}, vv[4] = {va[0], va[1], vb[0], vb[1]};
-        const double wc = w2[c];
-#pragma unroll
-        for (int y = 0; y < RY; ++y) {
-#pragma unroll
-          for (int x = 0; x < 4; ++x) mix[y][x] = cov_mix_term(mix[y][x], wc, uv[y], vv[x], sd[y][x], etab);
-          // four exp chains in flight, not eight: with the 128 accumulator registers live the scheduler's appetite for
-          // parallel chains otherwise ends in scratch (200 B per lane)
-          asm volatile("" : "+v"(mix[y][0]), "+v"(mix[y][1]), "+v"(mix[y][2]), "+v"(mix[y][3]));
-        }
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < RY; ++y) acc[x][y0 + y][r] = fma(scale, mix[y][x], post_shift) - acc[x][y0 + y][r];
-    }
-  }
-  double* Cl = C + row0 + 4 * l15 + (size_t)(col0 + 4 * l4) * ld;
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      d4 o;
-#pragma unroll
-      for (int y = 0; y < 4; ++y) o[y] = acc[x][y][r];
-      *(d4*)(Cl + (size_t)(16 * r + x) * ld) = o;
-    }
 }
 
 // ---- half-width strip with a four-stage ring (tail of an update launch) ---------------------------
@@ -1122,7 +1000,7 @@ __host__ __device__ inline int gemm_units_per_matrix(int mode, int nt, int j, in
 // One unit of block column j for matrix b: tile row i (i == nt: trsm's thin right-hand-side row; i > nt: extra rows),
 // column strip `strip` of S (or of g.tail_s ring strips).  Shared by the launch-per-phase kernels (gemm_dispatch maps
 // blockIdx to a unit) and the dataflow scheduler (chol_sched_kernel takes units from a queue).
-template <int MODE, int S, bool GEN = false>
+template <int MODE, int S>
 __device__ __forceinline__ void gemm_unit(const GemmArgs& g, double* smem, int j, int b, int i, int strip, bool ring) {
   const int ld = g.ld;
   double* Ab = g.A + (size_t)b * g.a_stride;
@@ -1172,15 +1050,6 @@ __device__ __forceinline__ void gemm_unit(const GemmArgs& g, double* smem, int j
       return;
     }
     if (!g.wide && fits_buffer_offsets(Kdim, ldP > ldQ ? ldP : ldQ)) {   // else: 64-bit-pointer loop, same bits
-      // GEN (chol_update_gen_kernel, CCGP_OPT_FUSED_COV): tile rows of the matrix proper that lie wholly inside n generate
-      // their covariance tile (the host decides per launch and keeps cov_kernel's tile list in step: GroupRun::begin).
-      // A kernel of its own: the generating epilogue needs 256 VGPRs and 200 B of scratch, the plain one neither.
-      if constexpr (GEN) {
-        if (i < g.nt && (i + 1) * kTile <= g.n) {
-          update_tile_il_gen(smem, P, ldP, Q, ldQ, Kdim, C, rld, g, b, i);
-          return;
-        }
-      }
       update_tile_il(smem, P, ldP, Q, ldQ, Kdim, C, rld);
       return;
     }
@@ -1205,7 +1074,7 @@ __device__ __forceinline__ void diag_unit(const GemmArgs& g, double* smem, int j
   }
 }
 
-template <int MODE, int S, bool GEN = false>
+template <int MODE, int S>
 __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
   const int L = blockIdx.x;
   int b, i, strip = 0;
@@ -1251,21 +1120,20 @@ __device__ __forceinline__ void gemm_dispatch(const GemmArgs& g, double* smem) {
       i = g.j + 1 + u;
     }
   }
-  gemm_unit<MODE, S, GEN>(g, smem, g.j, b, i, strip, ring);
+  gemm_unit<MODE, S>(g, smem, g.j, b, i, strip, ring);
 }
 
 // distinct kernel symbols per phase (rocprof attributes time per symbol) and per strip count
-#define CCGP_DEFINE_GEMM(NAME, MODE, S, WPS, GEN)                                       \
+#define CCGP_DEFINE_GEMM(NAME, MODE, S, WPS)                                            \
   __global__ __launch_bounds__(256, WPS) void NAME(GemmArgs g) {                        \
     extern __shared__ __attribute__((aligned(16))) double smem[];                       \
-    gemm_dispatch<MODE, S, GEN>(g, smem);                                                \
+    gemm_dispatch<MODE, S>(g, smem);                                                     \
   }
-CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2, false)
-CCGP_DEFINE_GEMM(chol_update_gen_kernel, 0, 1, 2, true)
-CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2, false)
+CCGP_DEFINE_GEMM(chol_update_kernel, 0, 1, 2)
+CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
 // trsm exists at S = 1 only: it is in place (reads the whole tile row, writes its own columns), so column
 // strips of one tile would race
-CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2, false)
+CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
 #undef CCGP_DEFINE_GEMM
 
 // ---- dataflow scheduler: the whole sweep of a chunk as ONE persistent launch --------------------------------------------
@@ -1446,9 +1314,9 @@ __device__ __forceinline__ void sched_run(const GemmArgs& g, double* smem, unsig
       diag_unit(g, smem, j, b);
     }
   } else if (kind == sched::kU) {
-    gemm_unit<0, 1, false>(g, smem, j, b, i, 0, false);
+    gemm_unit<0, 1>(g, smem, j, b, i, 0, false);
   } else {
-    gemm_unit<1, 1, false>(g, smem, j, b, i, 0, false);
+    gemm_unit<1, 1>(g, smem, j, b, i, 0, false);
   }
 }
 
@@ -1569,7 +1437,7 @@ __global__ void sched_check_kernel(const int* ctrl, int* status, int nb) {
 // block of K and per step; the second resident workgroup of a CU only fills bubbles); with the diagonal tile as ONE
 // long workgroup (it also factorises the block) whole launches of half-width strips no longer win anywhere
 // (profiles/r02_update_schedule.md sections 3 and 6).  The S = 2 kernel remains for the rows-only sweeps of
-// ccgp_predict_from_factorset (few, long rows) and as a measurement switch (CCGP_OPT_UPDATE_STRIPS).
+// ccgp_predict_from_factorset (few, long rows).
 
 // Tiles of an update launch that should run as strips: the launch is W1 = nb8 (1 + tiles) workgroups at S = 1 and
 // takes ceil(W1 / 256) steps (one workgroup per CU saturates its MFMA pipes).  If the last step holds `rem` <= 128
@@ -1605,8 +1473,7 @@ static void launch_gemm(hipStream_t s, GemmArgs g, int mode, int S) {
   }
   const dim3 grid(units), block(256);
   if (mode == 0) {
-    if (S == 1 && g.fuse_gen) hipLaunchKernelGGL(chol_update_gen_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
-    else if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
+    if (S == 1) hipLaunchKernelGGL(chol_update_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
     else hipLaunchKernelGGL(chol_update_s2_kernel, grid, block, gemm_lds_bytes<2>(), s, g);
   } else {
     hipLaunchKernelGGL(chol_trsm_kernel, grid, block, gemm_lds_bytes<1>(), s, g);
@@ -2153,77 +2020,12 @@ struct GroupRun {
   const BlockedJob* job;
   GemmArgs g{};
   DiagArgs dg{};
-  int force_s = 0;
-  std::vector<char> fused;   // per block column: whole tiles of its update launch generate their covariance tile
-
-  // Which block columns' update launches generate their own covariance tiles (update_tile_il_gen), and with that the
-  // list of 64 x 64 tiles cov_kernel still has to write: everything of block column 0 and of the columns that are not
-  // fused, and of the fused ones the diagonal tile and the tile rows that reach past n (identity padding).
-  // A column is fused when every one of its tiles below the diagonal runs through update_tile_il: Gaussian family, whole
-  // tiles (no strip option, no tail of ring strips in that launch: their epilogue has another lane layout), 32-bit
-  // buffer offsets, and the epilogue's LDS image within the k-loop's 64 KiB.
-  bool any_fused = false;
-  int plan_fusion() {
-    fused.assign(nt, 0);
-    const int nb8 = round_up(nb, 8), nfull = n / kTile;
-    const bool ok = dv.fam.id == 0 && h->opt_strips == 0 && !h->opt_wide_offsets && h->opt_fused_cov &&
-                    sizeof(double) * gen_lds_doubles(d, dv.K) <= gemm_lds_bytes<1>() &&
-                    (size_t)npad * (size_t)w.ld * 8 < 0xFFFF0000ull;
-    for (int j = 1; j < nt && ok; ++j) {
-      const int tiles = (nt - 1 - j) + w.ne;
-      int ts_ = 2;
-      const bool whole = !h->opt_tail_strips || update_tail(nb8, tiles, h->opt_tail_strips == 1, &ts_) == 0;
-      fused[j] = whole && ((size_t)j * kTile + 32) * (size_t)w.ld * 8 < 0xFFFF0000ull;   // fits_buffer_offsets(j * 128, ld)
-    }
-    any_fused = false;
-    for (int j = 1; j < nt; ++j) any_fused = any_fused || fused[j];
-    if (!any_fused) return 0;   // cov_kernel enumerates every lower tile itself: no list
-    h->tlist_host.clear();
-    const int nt64 = npad / 64;
-    for (int tr = 0; tr < nt64; ++tr)
-      for (int tc = 0; tc <= tr; ++tc) {
-        const int i = tr / 2, j = tc / 2;
-        if (j >= 1 && fused[j] && i > j && i < nfull) continue;   // generated by the update workgroup that consumes it
-        h->tlist_host.push_back(tr);
-        h->tlist_host.push_back(tc);
-      }
-    return (int)h->tlist_host.size() / 2;
-  }
-
   void begin() {
     const BlockedJob* pr = job && job->kind == kJobPredict ? job : nullptr;
     nt = npad / kTile;
     {
       ScopedTimer t(h, CCGP_T_COV, s);
-      const int ntl = plan_fusion();
-      const int* tlist = nullptr;
-      if (any_fused) {
-        // the list lives in a buffer of the handle's own (nothing else writes it) and depends on the shapes only: a caller
-        // that repeats them (a grid per step, Metro) uploads it once
-        if (h->tlist_cap < (size_t)ntl) {
-          if (h->tlist_dev) (void)hipFree(h->tlist_dev);
-          h->tlist_dev = nullptr;
-          h->tlist_cap = 0;
-          h->tlist_key.clear();
-          if (hipMalloc(&h->tlist_dev, sizeof(int) * 2 * (size_t)ntl) == hipSuccess) h->tlist_cap = (size_t)ntl;
-        }
-        if (h->tlist_cap < (size_t)ntl) {          // no list, no fusion: cov_kernel writes every tile
-          any_fused = false;
-          fused.assign(nt, 0);
-        } else {
-          const std::vector<long long> key{npad, n, nb, w.ne, h->opt_tail_strips, d, dv.K, ntl};
-          if (key != h->tlist_key) {
-            (void)hipMemcpyAsync(h->tlist_dev, h->tlist_host.data(), sizeof(int) * 2 * (size_t)ntl, hipMemcpyHostToDevice, s);
-            h->tlist_key = key;
-          }
-          tlist = h->tlist_dev;
-        }
-      }
-      h->plan_gen_columns = 0;
-      for (int j = 1; j < nt; ++j) h->plan_gen_columns += fused[j];
-      h->plan_cov_tiles = tlist ? ntl : (npad / 64) * (npad / 64 + 1) / 2;
-      launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld, w.xpad, w.upad,
-                       tlist, ntl);
+      launch_cov_tiles(s, X, n, d, dv, b0, nb, w.A, w.a_stride, npad, mean_mode, sigma2, tau2, w.ld, w.xpad, w.upad);
       RhsArgs ra{w.A, w.a_stride, npad, n, y, w.ld, job && job->kind >= kJobInverse ? 1 : 0};
       hipLaunchKernelGGL(rhs_rows_kernel, dim3(npad / 16, nb), dim3(256), 0, s, ra);
       if (pr)   // rows npad+128+t = r(x_t)' (Mixed.corr.vec, HX:425-431), one row per test site
@@ -2238,9 +2040,6 @@ struct GroupRun {
     dg.invd_stride = g.invd_stride; dg.logdet_part = w.z; dg.status = status + b0; dg.nt = nt;
     dg.nb = nb; dg.n = n; dg.ld = w.ld;
     dg.ptol = g.ptol = pivot_tolerance(mean_mode, n);
-    force_s = h->opt_strips;   // ccgp_set_option(CCGP_OPT_UPDATE_STRIPS): 0 = whole tiles (+ tail strips)
-    g.xpad = w.xpad; g.upad = w.upad; g.params = dv.params; g.ldp = dv.ldp; g.K = dv.K; g.d = d; g.draw0 = b0;
-    g.mean_mode = mean_mode; g.sigma2 = sigma2; g.tau2 = tau2;
   }
 
   // T_ij = A_ij - sum_{k<j} L_ik L_jk' for every tile row of block column j (nothing to do at j = 0)
@@ -2249,8 +2048,7 @@ struct GroupRun {
     ScopedTimer t(h, CCGP_T_UPDATE, s);
     g.j = j;
     g.mode = 0;
-    g.fuse_gen = fused[j];
-    launch_gemm(s, g, 0, force_s > 0 ? force_s : 1);
+    launch_gemm(s, g, 0, 1);
   }
 
   // L_jj, W_j = L_jj^-1, then L_ij = T_ij W_j' for the rows below
@@ -2329,7 +2127,7 @@ struct GroupRun {
     return (nt >= 16 && nb >= 32 && nb <= 128) ? 2 : 0;
   }
   bool scheduled() const {
-    return sched_mode() != 0 && h->opt_fuse_diag && !any_fused && force_s == 0 && sched::rows(sched::Shape{nt, w.ne, 0}) < 0x7fff &&
+    return sched_mode() != 0 && h->opt_fuse_diag && sched::rows(sched::Shape{nt, w.ne, 0}) < 0x7fff &&
            (size_t)nb * (size_t)sched::tasks_per_matrix(sched::Shape{nt, w.ne, 0}) < 0x7fffffffull;
   }
   void sweep_scheduled() {
@@ -2345,7 +2143,7 @@ struct GroupRun {
     const int init_blocks = (int)std::min<long>(2048, (total + 255) / 256 + 8);
     hipLaunchKernelGGL(sched_init_kernel, dim3(init_blocks), dim3(256), 0, s, ia);
     SchedArgs a{};
-    a.g = g; a.g.j = 0; a.g.mode = 0; a.g.fuse_gen = 0; a.g.n_s1 = 0; a.g.tail_s = 2;
+    a.g = g; a.g.j = 0; a.g.mode = 0; a.g.n_s1 = 0; a.g.tail_s = 2;
     a.ctrl = ctrl; a.slots = slots; a.counters = counters; a.cu_seen = cu_seen;
     a.policy = h->opt_sched_policy;
     a.backlog_min = h->sched_backlog_min > 0 ? h->sched_backlog_min : std::max(1, h->n_cus / 8);
@@ -2383,7 +2181,6 @@ void blocked_loglik(ccgp_handle* h, const double* X, int n, int d, const double*
   static unsigned long long attr_mask = 0;
   once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)chol_update_kernel, "chol_update_kernel");
-    raise_lds_limit((const void*)chol_update_gen_kernel, "chol_update_gen_kernel");
     raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
     raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
     raise_lds_limit((const void*)chol_sched_kernel, "chol_sched_kernel");
@@ -2420,7 +2217,6 @@ void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int
   static unsigned long long attr_mask = 0;
   once_per_device(attr_mask, [] {
     raise_lds_limit((const void*)chol_update_kernel, "chol_update_kernel");
-    raise_lds_limit((const void*)chol_update_gen_kernel, "chol_update_gen_kernel");
     raise_lds_limit((const void*)chol_update_s2_kernel, "chol_update_s2_kernel");
     raise_lds_limit((const void*)chol_trsm_kernel, "chol_trsm_kernel");
   });
@@ -2439,7 +2235,7 @@ void blocked_predict_from_factors(ccgp_handle* h, const BlockedWs& w, int n, int
       ScopedTimer t(h, CCGP_T_UPDATE, s);
       g.mode = 0;
       // few rows: two half-width strips double the workgroups of a launch that cannot fill the chip
-      launch_gemm(s, g, 0, h->opt_strips > 0 ? h->opt_strips : (nb8 * ne < 256 ? 2 : 1));
+      launch_gemm(s, g, 0, nb8 * ne < 256 ? 2 : 1);
     }
     {
       ScopedTimer t(h, CCGP_T_TRSM, s);

@@ -258,11 +258,10 @@ int loglik_dev(ccgp_handle* h, const double* dX, int n, int d, const double* dy,
   DrawView dv{dparams, B, K, d};
   dv.fam = h->fam;
   if (int frc = check_family(h, dv.fam, d, K)) return frc;
-  const bool force_lds = h->opt_small_lds != 0;   // ccgp_set_option(CCGP_OPT_SMALL_LDS): A/B switch for measurements
   // the fused evaluators generate Gaussian correlations in registers; any other family goes through
   // the materialised-matrix (blocked) path, where only cov_kernel knows about families
   const bool gauss = dv.fam.id == 0;
-  const bool reg_ok = gauss && small_reg_supported(n, d, K) && !force_lds;
+  const bool reg_ok = gauss && small_reg_supported(n, d, K);
   const bool lds_ok = gauss && n <= kSmallMaxN && small_lds_bytes(n, d, 0) <= (size_t)kLdsBytes - 64;
   if (reg_ok || lds_ok) {   // otherwise (n > 128, or d too large for LDS) the blocked path takes it
     ScopedTimer t(h, CCGP_T_FUSED);
@@ -531,7 +530,6 @@ int ccgp_destroy(ccgp_handle* h) try {
     (void)hipEventDestroy(s.e1);
   }
   if (h->ws) (void)hipFree(h->ws);
-  if (h->tlist_dev) (void)hipFree(h->tlist_dev);
   if (h->stage) (void)hipFree(h->stage);
   if (h->pin) (void)hipHostFree(h->pin);
   for (auto& e : h->pull_ev)
@@ -571,14 +569,6 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes) try {
 
 int ccgp_set_option(ccgp_handle* h, int option, int value) try {
   if (!h) return CCGP_EINVAL;
-  if (option == CCGP_OPT_UPDATE_STRIPS && (value == 0 || value == 1 || value == 2)) {
-    h->opt_strips = value;
-    return CCGP_OK;
-  }
-  if (option == CCGP_OPT_SMALL_LDS && (value == 0 || value == 1)) {
-    h->opt_small_lds = value;
-    return CCGP_OK;
-  }
   if (option == CCGP_OPT_TAIL_STRIPS && value >= 0 && value <= 2) {
     h->opt_tail_strips = value;
     return CCGP_OK;
@@ -593,10 +583,6 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
   }
   if (option == CCGP_OPT_SMALL_GRID16 && (value == 0 || value == 1)) {
     h->opt_small_grid16 = value;
-    return CCGP_OK;
-  }
-  if (option == CCGP_OPT_FUSED_COV && (value == 0 || value == 1)) {
-    h->opt_fused_cov = value;
     return CCGP_OK;
   }
   if (option == CCGP_OPT_SCHED && value >= 0 && value <= 3) {
@@ -666,13 +652,6 @@ int ccgp_last_sched_profile(ccgp_handle* h, unsigned long long* out, int max_wor
   if (out_workgroups) *out_workgroups = nw;
   if (nw > 0 && h->sched_prof_dev)
     CCGP_HIP(hipMemcpy(out, h->sched_prof_dev, sizeof(unsigned long long) * 8 * (size_t)nw, hipMemcpyDeviceToHost));
-  return CCGP_OK;
-} CCGP_GUARD_END(h)
-
-int ccgp_last_sweep_plan(ccgp_handle* h, int* out_generating_columns, int* out_cov_tiles) try {
-  if (!h) return CCGP_EINVAL;
-  if (out_generating_columns) *out_generating_columns = h->plan_gen_columns;
-  if (out_cov_tiles) *out_cov_tiles = h->plan_cov_tiles;
   return CCGP_OK;
 } CCGP_GUARD_END(h)
 
@@ -1012,7 +991,7 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
   if (int frc = check_family(h, dv.fam, d, K)) return frc;
   {
     ScopedTimer t(h, CCGP_T_FUSED);
-    if (small_reg_inverse_supported(n, d, K) && !h->opt_small_lds)
+    if (small_reg_inverse_supported(n, d, K))
       launch_small_reg_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst);
     else
       launch_small_grad(h->stream, dX, n, d, dy, dv, B, sigma2, dll, dbeta, dg, dst, dgp);
@@ -1071,8 +1050,8 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   int st = 0;
   CCGP_HIP(hipSetDevice(h->device));
   const bool gauss = h->fam.id == 0;
-  const bool reg_val = gauss && small_reg_supported(n, d, K) && !h->opt_small_lds;
-  const bool reg_inv = gauss && small_reg_inverse_supported(n, d, K) && !h->opt_small_lds;
+  const bool reg_val = gauss && small_reg_supported(n, d, K);
+  const bool reg_inv = gauss && small_reg_inverse_supported(n, d, K);
   const size_t in_d = (size_t)n * d + n + P;                       // X | y | row
   const size_t out_d = 3 + (out_Rinv ? (size_t)n * n : 0);         // ll, beta, status (as one double slot) | R^-1
   if ((out_Rinv ? reg_inv : reg_val) && ensure_pin(h, sizeof(double) * (in_d + out_d)) == CCGP_OK) {
@@ -1391,8 +1370,7 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   }
   {
     ScopedTimer t(h, CCGP_T_FUSED);
-    const bool force_lds = h->opt_small_lds != 0;
-    if (small_reg_supported(n, d, K, false, true) && !force_lds)
+    if (small_reg_supported(n, d, K, false, true))
       launch_small_reg_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
                                d_status);
     else

@@ -66,15 +66,7 @@ struct ccgp_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   size_t ws_limit = size_t(24) << 30;   // ccgp_create replaces this by 3/4 of the device's memory
-  int opt_strips = 0;                   // CCGP_OPT_UPDATE_STRIPS
-  int opt_small_lds = 0;                // CCGP_OPT_SMALL_LDS
   int opt_small_grid16 = 0;             // CCGP_OPT_SMALL_GRID16
-  int opt_fused_cov = 0;                // CCGP_OPT_FUSED_COV
-  std::vector<int> tlist_host;          // cov_kernel's tile list as the last plan built it (host image of tlist_dev)
-  std::vector<long long> tlist_key;     // shapes and options the list in tlist_dev was built for
-  int* tlist_dev = nullptr;             // device copy of the list (CCGP_OPT_FUSED_COV only), tlist_cap pairs
-  size_t tlist_cap = 0;
-  int plan_gen_columns = 0, plan_cov_tiles = 0;   // ccgp_last_sweep_plan
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
   int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
@@ -124,12 +116,10 @@ void launch_cov_dense(hipStream_t s, const double* A, int m, const double* Bm, i
 // s*R_mixed + t into the lower tiles of an npad x npad column-major matrix (identity on
 // the padding), z in [0, nb).  scale/shift: mode 0 -> (1, 0); mode 1 -> (sigma2*sum w^2, tau2).
 // upad (nb x K x npad): u[z][c][i] = sum_k theta_ck x_ik^2 of draw b0 + z, written here once per draw and read by every
-// covariance tile of that draw -- by cov_kernel and by the update workgroups that generate their own tile (blocked.hip).
-// tlist / ntl: the 64 x 64 lower tiles (row tile, column tile) to write, the same list for every matrix; nullptr: all of them.
+// covariance tile of that draw.
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2, int ld, double* xpad = nullptr, double* upad = nullptr,
-                      const int* tlist = nullptr, int ntl = 0);
+                      double tau2, int ld, double* xpad = nullptr, double* upad = nullptr);
 void launch_cov_cross_batched(hipStream_t s, const double* Xtest, int m, const double* X, int n, int d,
                               DrawView dv, int b0, int nb, double* Abase, size_t batch_stride, int ldo);
 
@@ -301,8 +291,7 @@ __device__ __forceinline__ double exp_cov(double dist, const double* tab) {
 }
 
 // One component's term of one mixed-covariance entry: acc + w_c^2 exp(-((u_row + u_col) - 2 sdot)) (HX:352-356, HX:412), in
-// the ONE operation order both producers of a blocked-path entry use -- cov_kernel and the update workgroups that generate
-// their own tile (blocked.hip) -- so that which of them produced a tile cannot be seen in the bits.
+// ONE operation order for every producer of a blocked-path entry.
 __device__ __forceinline__ double cov_mix_term(double acc, double wc, double u_row, double u_col, double sdot,
                                                const double* tab) {
   const double dist = fma(-2.0, sdot, u_row + u_col);

@@ -38,7 +38,6 @@ struct CovArgs {
   int raw_mix;      // 1: sum w_c^2 r_c without the division by sum w_c^2 (corr.vec.combined as written, D1F:470-480)
   const double* colpad;   // SCOL instantiation: the design zero-padded to npad rows (npad x d, leading dimension npad)
   const double* upad;     // SCOL instantiation: u[z][c][i] (nb x K x npad), written by cov_u_kernel
-  const int* tlist;       // lower_tiles: (row tile, column tile) pairs to write; nullptr = every lower tile
 };
 
 // LDS: etab[256] | xa[d][64] | xb[d][64] | ua[K][64] | ub[K][64] | th[K][d] | w2[K]
@@ -57,10 +56,7 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   double* w2 = th + K * d;
 
   int tr = blockIdx.x, tc = blockIdx.y;
-  if (a.lower_tiles && a.tlist) {
-    tr = a.tlist[2 * blockIdx.x];
-    tc = a.tlist[2 * blockIdx.x + 1];
-  } else if (a.lower_tiles) {
+  if (a.lower_tiles) {
     // triangular launch: blockIdx.x enumerates (tr >= tc) pairs of 64-wide tiles
     int t = blockIdx.x;
     int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -277,7 +273,7 @@ __global__ void cov_u_kernel(const double* xpad, int npad, int d, const double* 
 
 void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv, int b0, int nb,
                       double* Abase, size_t batch_stride, int npad, int mean_mode, double sigma2,
-                      double tau2, int ld, double* xpad, double* upad, const int* tlist, int ntl) {
+                      double tau2, int ld, double* xpad, double* upad) {
   CovArgs a{};
   a.A = X; a.Bm = X; a.m = n; a.n = n; a.d = d;
   a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K; a.fam = dv.fam; a.draw0 = b0;
@@ -285,8 +281,7 @@ void launch_cov_tiles(hipStream_t s, const double* X, int n, int d, DrawView dv,
   a.sigma2 = sigma2; a.tau2 = tau2; a.lower_tiles = 1; a.npad = npad;
   cov_prepare();
   int nt64 = npad / 64;
-  dim3 grid(tlist ? ntl : nt64 * (nt64 + 1) / 2, 1, nb);
-  a.tlist = tlist;
+  dim3 grid(nt64 * (nt64 + 1) / 2, 1, nb);
   // the scalar-column instantiation addresses a matrix through 32-bit buffer offsets
   const bool fits32 = (size_t)npad * (size_t)ld * 8 < 0xFFFF0000ull;
   if (dv.fam.id == 0 && xpad && upad && fits32) {

@@ -93,10 +93,9 @@ int ccgp_set_kernel(ccgp_handle* h, int family, double nu);
 /* cap on device scratch used per launch group; larger batches are processed in chunks.  Default: three
  * quarters of the device's memory (216 of 288 GB on MI355X), and never more than is free at call time. */
 int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
-/* measurement switches (A/B runs under rocprof; results do not depend on them):
- *   CCGP_OPT_UPDATE_STRIPS  0 = library's choice (default; S = 1 since round 2), 1 | 2 = pin the column-strip count of the
- *                           blocked Cholesky's trailing-update launches
- *   CCGP_OPT_SMALL_LDS      1 = run n <= 128 on the in-LDS evaluator instead of the register-resident one
+/* measurement switches (A/B runs under rocprof; results do not depend on them).  Option numbers 0, 1 and 6 were
+ * CCGP_OPT_UPDATE_STRIPS, CCGP_OPT_SMALL_LDS and CCGP_OPT_FUSED_COV of rounds 1 - 4 (removed in round 5: no caller outside
+ * tests; the fused covariance generation measured 0.3 % and is kept as profiles/r05/fused_cov_removed.diff) and are refused.
  *   CCGP_OPT_FUSE_DIAG      1 (default) = the update launch's diagonal-tile workgroup also factorises and inverts
  *                           the diagonal block; 0 = a separate diag_kernel launch per block column
  *   CCGP_OPT_TAIL_STRIPS    1 (default) = the tiles of an update launch's last, partial step of 256 workgroups run
@@ -107,11 +106,7 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           fall back to (same bits: the tests hold one against the other)
  *   CCGP_OPT_SMALL_GRID16   0 (default) = 64 < n <= 104 runs ONE wave per matrix on the 8 x 8 thread grid (up to 13 x 13
  *                           blocks per thread); 1 = the 16 x 16 grid (one workgroup per matrix) of rounds 1 - 3 (same bits)
- *   CCGP_OPT_FUSED_COV      0 (default) = cov_kernel writes every lower tile of the covariance matrix and the trailing update
- *                           reads them; 1 = whole tiles of the update generate their covariance tile in their own epilogue
- *                           and cov_kernel writes only the rest (same bits: the tests hold one against the other; a third
- *                           less HBM traffic per evaluation at n = 4096 for 0.3 - 0.6 % of its time) */
-/*   CCGP_OPT_SCHED          the blocked Cholesky sweep of a chunk (n > 128): 0 = one launch per phase and block column
+ *   CCGP_OPT_SCHED          the blocked Cholesky sweep of a chunk (n > 128): 0 = one launch per phase and block column
  *                           (rounds 1 - 4); 1 = ONE persistent launch whose workgroups take diagonal / update / panel-solve
  *                           tiles from dependency-driven queues, two workgroups per CU; 2 = the same with one workgroup per CU;
  *                           3 (default) = 2 for chunks of 32 ... 128 matrices with n >= 2048, where it measures ahead, else 0.
@@ -124,9 +119,8 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           own arrivals made ready instead of queueing it; bit 4 (tests only): drop the announcements of
  *                           matrix 0's second block column, so that the sweep cannot finish -- it must then abort after
  *                           CCGP_SCHED_TIMEOUT_MS (environment, default 30000) and fail every evaluation of the chunk, not hang */
-enum { CCGP_OPT_UPDATE_STRIPS = 0, CCGP_OPT_SMALL_LDS = 1, CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3,
-       CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5, CCGP_OPT_FUSED_COV = 6, CCGP_OPT_SCHED = 7,
-       CCGP_OPT_SCHED_POLICY = 8 };
+enum { CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3, CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5,
+       CCGP_OPT_SCHED = 7, CCGP_OPT_SCHED_POLICY = 8 };
 int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);
@@ -311,10 +305,6 @@ enum {
 /* on = 0: off; 1: every id; otherwise a mask with bit (1 + id) set for each id to time */
 int ccgp_enable_timing(ccgp_handle* h, int on);
 int ccgp_get_timing(ccgp_handle* h, int id, double* out_ms, int* out_launches);
-/* What the LAST blocked sweep (n > 128) of this handle planned -- a diagnostic beside the timers: the number of block columns
- * whose trailing update generated its covariance tiles (0 unless CCGP_OPT_FUSED_COV) and the number of 64 x 64 tiles per matrix
- * left to the covariance kernel (all n_pad/64 (n_pad/64 + 1) / 2 lower tiles when nothing is generated). */
-int ccgp_last_sweep_plan(ccgp_handle* h, int* out_generating_columns, int* out_cov_tiles);
 /* With CCGP_OPT_SCHED_POLICY bit 2 set, the scheduled sweep keeps a time account per workgroup (8 words each, ticks of 10 ns:
  * waiting for a task, in diagonal / update / panel-solve tiles, applying arrivals; then tasks run, XCD served, 1 if second on
  * its CU).  Copies the account of the LAST scheduled sweep (synchronises the stream). */

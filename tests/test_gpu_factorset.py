@@ -61,16 +61,6 @@ def test_n520_blocked_path_two_test_sets(handle):
             handle.set_workspace_limit(200 << 30)
         np.testing.assert_array_equal(chunked[0], whole[0])
         np.testing.assert_array_equal(chunked[1], whole[1])
-        # few rows run as half-width strips by default; pinned to whole tiles the scratch rows go through the round-3
-        # tile loop with their own leading dimension (row panel from E, column panel from the factor): same bits
-        from ccgp_amd import api
-        handle.set_option(api.OPT_UPDATE_STRIPS, 1)
-        try:
-            tiles = fs.predict(sets[1])
-        finally:
-            handle.set_option(api.OPT_UPDATE_STRIPS, 0)
-        np.testing.assert_array_equal(tiles[0], whole[0])
-        np.testing.assert_array_equal(tiles[1], whole[1])
     # oracle for one draw and a few sites
     w, Th = orc.unpack_params(P[0], 2, 3)
     R = orc.mixed_corr_matrix_general(X, w, Th)

@@ -540,83 +540,6 @@ def test_update_loops_with_buffer_offsets_and_with_pointers_give_the_same_bits(h
     assert got[0][0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.3)[0], rel=1e-9)
 
 
-@pytest.mark.parametrize("n,d,K,B,tail", [(300, 4, 2, 9, 0), (1100, 5, 3, 8, 0), (1024, 5, 3, 16, 0), (1537, 2, 4, 3, 0),
-                                         (640, 5, 3, 256, 1), (1000, 3, 2, 128, 1)])
-def test_covariance_generated_in_the_update_and_read_from_hbm_give_the_same_bits(handle, n, d, K, B, tail):
-    """OPT_FUSED_COV (round 4): a whole tile of the trailing update generates its covariance tile in the epilogue of the
-    workgroup that consumes it (blocked.hip: update_tile_il_gen, chol_update_gen_kernel) and cov_kernel writes only the tiles
-    of a host-built list (column 0, diagonal tiles, ragged edge rows, columns whose launch has tail strips).  Both evaluate
-    every entry through cov_mix_term on the same u = sum theta x^2 table, so the default data flow (cov_kernel writes
-    everything, the update reads it) must give the same bits: log-likelihood in both mean modes (a failing draw included), prediction (extra tile
-    rows) and gradient (identity rows); n a multiple of 128 and ragged, draw counts with and without a ragged group.
-    A block column generates only if its launch has no tail strips: the small batches run with OPT_TAIL_STRIPS off (every
-    tile whole), the large ones as they come (256 matrices: whole steps; 128: every other block column) -- and the plan is asserted."""
-    from ccgp_amd import api
-    X, y = synthetic_design(n, d, seed=5 * n)
-    rng = np.random.default_rng(n + B)
-    P = np.empty((B, K + K * d))
-    for b in range(B):
-        w = rng.dirichlet(np.ones(K))
-        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
-        th[-1] = np.maximum(th[-1], 2.0 * n ** (2.0 / d) / d)
-        P[b] = np.concatenate([w, th.ravel()])
-    P[B - 1, K:] = 0.0                               # R = 11': the factorisation fails in block column 0 or 1
-    Xt = rng.random((70, d))
-    def run():
-        out = []
-        for mode, tau2 in ((api.MEAN_PROFILE_BETA, 0.0), (api.MEAN_ZERO_PLUS_TAU2, 4.0)):
-            out += list(handle.loglik_batch(X, y, K, P, 1.3, mode, tau2))
-        out += list(handle.predict_batch(X, y, K, P[:2], Xt, 1.3))
-        out += list(handle.loglik_grad_batch(X, y, K, P[:2], 1.3))
-        return out
-    handle.set_option(api.OPT_TAIL_STRIPS, tail)
-    try:
-        want = run()
-        handle.set_option(api.OPT_FUSED_COV, 1)
-        got = run()
-        handle.loglik_batch(X, y, K, P, 1.3)
-        generating, cov_tiles = handle.last_sweep_plan()
-    finally:
-        handle.set_option(api.OPT_FUSED_COV, 0)
-        handle.set_option(api.OPT_TAIL_STRIPS, 1)
-    nt64 = (n + 127) // 128 * 2
-    assert generating >= 1 and (cov_tiles < nt64 * (nt64 + 1) // 2 or n // 128 < 3), (generating, cov_tiles)   # n = 300: no whole tile below block column 1
-    for a, b in zip(got, want):
-        np.testing.assert_array_equal(a, b)
-    assert got[2][B - 1] != 0 and not got[2][:B - 1].any() and np.isfinite(got[0][:B - 1]).all()
-    w, Th = orc.unpack_params(P[0], K, d)
-    assert got[0][0] == pytest.approx(orc.loglik_general(X, y, w, Th, 1.3)[0], rel=1e-8)
-
-
-def test_fused_generation_leaves_cov_kernel_only_the_listed_tiles(handle):
-    """What the option switches, read back from the sweep's plan (ccgp_last_sweep_plan): at n = 1024 (8 tile rows of 128 = 16
-    of 64: 136 lower 64 x 64 tiles per matrix) and 256 matrices (every launch a whole number of steps: no tail strips) each
-    block column from 1 on generates -- cov_kernel keeps block column 0 (31 tiles) and the other diagonal tiles (7 x 3) --; at a
-    ragged n the last tile row stays with cov_kernel too (24 more); with the option off nothing generates and every tile is
-    cov_kernel's.  (A plan that silently fused nothing would still pass the bitwise test above.)"""
-    from ccgp_amd import api
-    d, K, B = 5, 3, 256
-    rng = np.random.default_rng(11)
-    P = np.empty((B, K + K * d))
-    for b in range(B):
-        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
-        th[-1] = np.maximum(th[-1], 20.0)
-        P[b] = np.concatenate([rng.dirichlet(np.ones(K)), th.ravel()])
-    for n, want_cols, want_tiles in ((1024, 7, 31 + 21), (1000, 7, 31 + 21 + 24)):
-        X, y = synthetic_design(n, d, seed=11)
-        a = handle.loglik_batch(X, y, K, P, 1.0)
-        assert handle.last_sweep_plan() == (0, 136)
-        handle.set_option(api.OPT_FUSED_COV, 1)
-        try:
-            b = handle.loglik_batch(X, y, K, P, 1.0)
-            plan = handle.last_sweep_plan()
-        finally:
-            handle.set_option(api.OPT_FUSED_COV, 0)
-        np.testing.assert_array_equal(a[0], b[0])
-        assert not a[2].any() and not b[2].any()
-        assert plan == (want_cols, want_tiles), (n, plan)
-
-
 @pytest.mark.parametrize("n,B", [(1100, 64), (1100, 16), (700, 9), (1537, 40)])
 def test_tail_tiles_whole_as_half_strips_and_as_quarter_strips_give_the_same_bits(handle, n, B):
     """The tiles of an update launch's last, partial step of 256 workgroups run whole (OPT_TAIL_STRIPS 0), as two half-width
@@ -838,7 +761,7 @@ def test_gradient_matches_finite_differences(handle, case):
 def test_register_resident_gradient_wide_design_three_components_and_a_failed_draw(handle):
     """The n <= 128 gradient (round 3: `small_reg_kernel<16, NB, NB + 1, gradient>`) beyond the reference's shapes:
     d = 20 (two groups of 16 per-dimension accumulators), K = 3, n = 45 (not a multiple of 16), a batch in which one
-    draw is exactly singular (all scales 0: R = 11'), and agreement with the in-LDS kernel it replaced."""
+    draw is exactly singular (all scales 0: R = 11')."""
     from ccgp_amd import api
     rng = np.random.default_rng(31)
     n, d, K = 45, 20, 3
@@ -854,12 +777,6 @@ def test_register_resident_gradient_wide_design_three_components_and_a_failed_dr
         assert ll[b] == pytest.approx(orc.loglik_general(X, y, w, Th, 2.0)[0], rel=1e-9)
         fd = orc.loglik_grad_fd(X, y, rows[b], K, d, 2.0)
         np.testing.assert_allclose(grad[b], fd, rtol=2e-5, atol=2e-5 * np.abs(fd).max())
-    handle.set_option(api.OPT_SMALL_LDS, 1)                 # the in-LDS kernel of rounds 1-2
-    try:
-        _, _, g_lds, _ = handle.loglik_grad_batch(X, y, K, rows[[0, 1, 3]], 2.0)
-    finally:
-        handle.set_option(api.OPT_SMALL_LDS, 0)
-    np.testing.assert_allclose(grad[[0, 1, 3]], g_lds, rtol=1e-9, atol=1e-12 * np.abs(g_lds).max())
 
 
 # ------------------------------------------------------------------------------- 8(f)-4 entropy criteria
@@ -1119,8 +1036,9 @@ def test_widest_design_and_largest_chunks(handle):
     np.testing.assert_array_equal(beta[pick], beta2)
     with pytest.raises(api.CcgpError):
         handle.set_option(99, 1)
-    with pytest.raises(api.CcgpError):
-        handle.set_option(api.OPT_UPDATE_STRIPS, 3)
+    for removed in (0, 1, 6):       # CCGP_OPT_UPDATE_STRIPS / SMALL_LDS / FUSED_COV of rounds 1 - 4
+        with pytest.raises(api.CcgpError):
+            handle.set_option(removed, 1)
 
 
 @pytest.mark.parametrize("n", [65, 72, 81, 96, 100, 104])

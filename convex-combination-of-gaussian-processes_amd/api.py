@@ -51,6 +51,7 @@ SIGNATURES = {
                                        _dp, _dp, _dp, _ip]),
     "ccgp_logpost": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_double, c_int, _dp, _dp, _dp, _dp,
                              _dp, _dp, _ip]),
+    "ccgp_logpost_batch": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_double, c_int, _dp, c_int, _dp, _dp, _dp, _dp, _ip]),
     "ccgp_grid_marginal": (c_int, [c_void_p, _dp, c_int, c_int, _dp, c_double, _dp, c_int, c_int,
                                    c_double, c_int, c_double, _dp, _ip, _dp]),
     "ccgp_mixed_logdet_designs": (c_int, [c_void_p, _dp, c_int, c_int, c_int, c_int, _dp, _dp, _ip]),
@@ -471,6 +472,20 @@ class Handle:
                                      _p(theta_t), _p(pp), ctypes.byref(val), ctypes.byref(beta),
                                      ctypes.byref(ll), _p(Rinv), ctypes.byref(st)))
         return dict(val=val.value, beta=beta.value, loglik=ll.value, R_inv=Rinv, status=st.value)
+
+    def logpost_batch(self, X, y, sigma2, prior_id, theta_t, prior_pars=None):
+        """ccgp_logpost_batch: logpost of B transformed parameter vectors (rows of theta_t) in one call ->
+        (val, beta, loglik, status), each value as Handle.logpost returns it, bit for bit."""
+        X, y = _f(X), _f(np.ravel(y))
+        n, d = X.shape
+        theta_t = _f(np.atleast_2d(theta_t))
+        B = theta_t.shape[0]
+        pp = _f(np.ravel(prior_pars)) if prior_pars is not None else None
+        val, beta, ll = np.empty(B), np.empty(B), np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        self._chk(lib().ccgp_logpost_batch(self._h, _p(X), n, d, _p(y), float(sigma2), int(prior_id), _p(theta_t), B,
+                                           _p(pp), _p(val), _p(beta), _p(ll), _ipt(st)))
+        return val, beta, ll, st
 
     def grid_marginal(self, X, y, sigma2, hyper, N, tau, take_log, aniso_lambda=-1.0, want_logs=False):
         X, y = _f(X), _f(np.ravel(y))

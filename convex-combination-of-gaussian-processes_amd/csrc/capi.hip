@@ -1006,6 +1006,72 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
 } CCGP_GUARD_END(h)
 
 // ---- a8: logpost ------------------------------------------------------------------------------
+// One transformed parameter vector (psi1, psi2, phi[, zeta]) = (log theta1, log theta2, logit p[, log lambda]) -> the C-ABI
+// parameter row (w_1, w_2, theta_1k.., theta_2k..), the log-Jacobian and the script's log-prior (HX:446-463, GV:450, ISO:453,
+// ANI:459-462).  theta_t / row: element j of vector b at [b + j * ld]; shared by ccgp_logpost and ccgp_logpost_batch so that a
+// value does not depend on which of the two produced it.
+static void logpost_terms(int prior_id, int d, const double* theta_t, int ldt, const double* prior_pars, double* row,
+                          int ldr, double* log_jacob, double* log_prior) {
+  const double psi1 = theta_t[0], psi2 = theta_t[ldt], phi = theta_t[2 * (size_t)ldt];
+  const double theta1 = std::exp(psi1), theta2 = std::exp(psi2);
+  const double p = 1.0 / (1.0 + std::exp(-phi));
+  row[0] = p;
+  row[ldr] = 1.0 - p;
+  double lj = -phi - 2.0 * std::log(1.0 + std::exp(-phi)) + psi1 + psi2;
+  double lp = 0.0;
+  if (prior_id == CCGP_PRIOR_ANI) {
+    const double zeta = theta_t[3 * (size_t)ldt], lambda = std::exp(zeta);
+    row[2 * (size_t)ldr] = theta1; row[3 * (size_t)ldr] = theta2;
+    row[4 * (size_t)ldr] = (1.0 + lambda) * theta1; row[5 * (size_t)ldr] = (1.0 + lambda) * theta2;
+    lj += zeta;
+    lp = -psi1 - psi1 * psi1 / 2.0 - psi2 - psi2 * psi2 / 2.0 - 4.0 * zeta - 4.0 / lambda;
+  } else {
+    for (int k = 0; k < d; ++k) { row[(size_t)(2 + k) * ldr] = theta1; row[(size_t)(2 + d + k) * ldr] = theta2; }
+    if (prior_id == CCGP_PRIOR_INVGAMMA)
+      lp = -(prior_pars[0] + 1.0) * psi1 - prior_pars[1] / theta1 -
+           (prior_pars[2] + 1.0) * psi2 - prior_pars[3] / theta2;
+    else if (prior_id == CCGP_PRIOR_GV)
+      lp = -4.0 * psi1 - 1.0 / theta1 - 6.0 * psi2 - 75.0 / theta2;
+    else
+      lp = -4.0 * psi1 - 2.0 / theta1 - 6.0 * psi2 - 16.0 / theta2;
+  }
+  *log_jacob = lj;
+  *log_prior = lp;
+}
+
+int ccgp_logpost_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2, int prior_id,
+                       const double* theta_t, int B, const double* prior_pars, double* out_val, double* out_beta,
+                       double* out_loglik, int* status) try {
+  if (!h) return CCGP_EINVAL;
+  if (n < 1 || d < 1 || d > kMaxD || B < 1 || !X || !y || !theta_t || !out_val)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost_batch: bad argument");
+  if (prior_id < CCGP_PRIOR_INVGAMMA || prior_id > CCGP_PRIOR_ANI)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost_batch: unknown prior_id");
+  if (prior_id == CCGP_PRIOR_INVGAMMA && !prior_pars)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost_batch: prior_pars required for CCGP_PRIOR_INVGAMMA");
+  if (prior_id == CCGP_PRIOR_ANI && d != 2)
+    return fail(h, CCGP_EINVAL, "ccgp_logpost_batch: the anisotropic script (ANI) is 2-D");
+  const int K = 2, P = K + K * d;
+  std::vector<double> rows((size_t)B * P), ljac(B), lpri(B), ll(B), beta(B);
+  std::vector<int> st(B);
+  for (int b = 0; b < B; ++b) {
+    double lj = 0.0, lp = 0.0;
+    logpost_terms(prior_id, d, theta_t + b, B, prior_pars, rows.data() + b, B, &lj, &lp);
+    ljac[b] = lj;
+    lpri[b] = lp;
+  }
+  const int rc = ccgp_loglik_batch(h, X, n, d, y, K, rows.data(), B, sigma2, CCGP_MEAN_PROFILE_BETA, 0.0, ll.data(), beta.data(),
+                                   st.data());
+  if (rc < 0) return rc;
+  for (int b = 0; b < B; ++b) {
+    out_val[b] = ll[b] + ljac[b] + lpri[b];   // ccgp_logpost's order of additions; NaN where the factorisation failed: the reference's NA
+    if (out_beta) out_beta[b] = beta[b];
+    if (out_loglik) out_loglik[b] = ll[b];
+    if (status) status[b] = st[b];
+  }
+  return rc;
+} CCGP_GUARD_END(h)
+
 int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2,
                  int prior_id, const double* theta_t, const double* prior_pars, double* out_val,
                  double* out_beta, double* out_loglik, double* out_Rinv, int* status) try {
@@ -1018,31 +1084,10 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
     return fail(h, CCGP_EINVAL, "ccgp_logpost: prior_pars required for CCGP_PRIOR_INVGAMMA");
   if (prior_id == CCGP_PRIOR_ANI && d != 2)
     return fail(h, CCGP_EINVAL, "ccgp_logpost: the anisotropic script (ANI) is 2-D");
-  const double psi1 = theta_t[0], psi2 = theta_t[1], phi = theta_t[2];
-  const double theta1 = std::exp(psi1), theta2 = std::exp(psi2);
-  const double p = 1.0 / (1.0 + std::exp(-phi));
   const int K = 2, P = K + K * d;
   std::vector<double> row(P);
-  row[0] = p;
-  row[1] = 1.0 - p;
-  double log_jacob = -phi - 2.0 * std::log(1.0 + std::exp(-phi)) + psi1 + psi2;
-  double log_prior = 0.0;
-  if (prior_id == CCGP_PRIOR_ANI) {
-    const double zeta = theta_t[3], lambda = std::exp(zeta);
-    row[2] = theta1; row[3] = theta2;
-    row[4] = (1.0 + lambda) * theta1; row[5] = (1.0 + lambda) * theta2;
-    log_jacob += zeta;
-    log_prior = -psi1 - psi1 * psi1 / 2.0 - psi2 - psi2 * psi2 / 2.0 - 4.0 * zeta - 4.0 / lambda;
-  } else {
-    for (int k = 0; k < d; ++k) { row[2 + k] = theta1; row[2 + d + k] = theta2; }
-    if (prior_id == CCGP_PRIOR_INVGAMMA)
-      log_prior = -(prior_pars[0] + 1.0) * psi1 - prior_pars[1] / theta1 -
-                  (prior_pars[2] + 1.0) * psi2 - prior_pars[3] / theta2;
-    else if (prior_id == CCGP_PRIOR_GV)
-      log_prior = -4.0 * psi1 - 1.0 / theta1 - 6.0 * psi2 - 75.0 / theta2;
-    else
-      log_prior = -4.0 * psi1 - 2.0 / theta1 - 6.0 * psi2 - 16.0 / theta2;
-  }
+  double log_jacob = 0.0, log_prior = 0.0;
+  logpost_terms(prior_id, d, theta_t, 1, prior_pars, row.data(), 1, &log_jacob, &log_prior);
   // ONE factorisation per call (the reference runs two: solve(R) at HX:454 and the Cholesky inside dmnorm at
   // HX:460): without R.Inv the batched evaluator; with it, a sweep that carries y', 1' AND the identity rows,
   // so the likelihood, beta and R^-1 come out of the same elimination

@@ -69,8 +69,15 @@ def transformed_to_draws(theta_t):
 
 def logpost_batch(gp, D_train, theta_t, y, sigma2, prior_pars=None):
     """`logpost(...)$val` for MANY transformed draws in one device call -> (val, beta).
-    Rows whose covariance cannot be factorised give NaN (the reference's NA, HX:454-455)."""
+    Rows whose covariance cannot be factorised give NaN (the reference's NA, HX:454-455).
+    The Gaussian-kernel scripts go through ccgp_logpost_batch, whose Jacobian and prior arithmetic is the C code of the
+    one-at-a-time ccgp_logpost: a value is the same bits whichever call produced it (the chain of Metro(speculate = m), the
+    R shim's ccgp_R_metro_steps and the sequential chain are then the same chain)."""
     t = np.atleast_2d(np.asarray(theta_t, dtype=np.float64))
+    cfg = getattr(gp, "cfg", None)
+    if cfg is not None and hasattr(gp.h, "logpost_batch") and gp.script in ("HX", "ADV", "GV", "ISO", "BSQ", "ANI"):
+        val, beta, _, _ = gp.h.logpost_batch(D_train, y, sigma2, cfg["prior"], t, prior_pars)
+        return val, beta
     draws = transformed_to_draws(t)
     params = gp.draws_to_params(D_train, draws)
     ll, beta, _ = gp.h.loglik_batch(D_train, y, 2, params, sigma2, api.MEAN_PROFILE_BETA, 0.0)

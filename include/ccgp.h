@@ -176,6 +176,15 @@ int ccgp_loglik_grad_batch(ccgp_handle* h, const double* X, int n, int d, const 
 int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2,
                  int prior_id, const double* theta_t, const double* prior_pars, double* out_val,
                  double* out_beta, double* out_loglik, double* out_Rinv, int* status);
+/* logpost of B transformed parameter vectors in one call -- the candidates of a speculative block of Metro (HX:505-512: the
+ * random numbers of an iteration do not depend on accept / reject, so the 2^m - 1 candidates the chain can reach over the next
+ * m iterations are known up front; r/ccgp_shim.c: ccgp_R_metro_steps), or a population of starting points.  theta_t is B x q
+ * column-major, q = 3 (4 for CCGP_PRIOR_ANI).  val / beta / loglik per row exactly as ccgp_logpost returns them (same device
+ * evaluator, same host arithmetic for Jacobian and prior: same bits); NaN and status != 0 where the factorisation fails.
+ * Replaces B calls of logpost HX:441-466 (GV:429-454, ISO:433-457, ADV:447-471, ANI:433-467, D1:609-641, D1F:576-602). */
+int ccgp_logpost_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2, int prior_id,
+                       const double* theta_t, int B, const double* prior_pars, double* out_val, double* out_beta,
+                       double* out_loglik, int* status);
 
 /* ---- a9: likeli.hyperpars HX:549-575 / choose.hyperpars HX:584-595, ADV:552-599 -------
  * hyper is G x 4 (alpha1 beta1 alpha2 beta2).  For each row: N base-2 Halton quantiles

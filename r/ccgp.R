@@ -20,6 +20,9 @@
 #                                  #   instead of S x (5 + 2n + n^2); FALSE: the frame exactly as the script builds it
 #     ccgp.adv.as.written <- FALSE # ADV only: TRUE keeps predict.post's theta1 * (1 + lambda) second scale (ADV:672)
 #                                  #   through the literal per-draw path instead of the training kernel (ADV:417)
+#     ccgp.metro.block <- 4        # Metro evaluates the next 4 iterations' 2^4 - 1 candidates in ONE device call
+#                                  #   (same chain, same RNG stream: see Metro below); 1 = the script's own Metro, one logpost
+#                                  #   per proposal
 # Every index into a frame or a frame row is computed in r/ccgp_shim.c (executed by the test-suite), not here.
 # Not executable in this repository's build container (no R); see INTEGRATION.md.
 
@@ -28,6 +31,7 @@ dyn.load(Sys.getenv("CCGP_R_SHIM", "ccgpR.so"))
 if (!exists("ccgp.script")) ccgp.script <- "HX"
 if (!exists("ccgp.slim.frame")) ccgp.slim.frame <- TRUE
 if (!exists("ccgp.adv.as.written")) ccgp.adv.as.written <- FALSE
+if (!exists("ccgp.metro.block")) ccgp.metro.block <- 4L
 # ADV as written goes through the literal per-draw predict.post, which reads R.Inv and the factors from every frame row:
 # a slim frame (7 numbers per row) would make every prediction NA, so that option implies the full frame
 if (ccgp.script == "ADV" && ccgp.adv.as.written) ccgp.slim.frame <- FALSE
@@ -124,6 +128,75 @@ predict.post <- function(x.new, D.train, pars, sigma2, nu = 0) {
                .ccgp.layout.written, as.double(nu))
   colnames(out) <- c("mean", "var")
   out
+}
+
+# ---- the sampling phase on the batched path -----------------------------------------------------------------
+# Metro (HX:483-540 and its per-script copies) asks for ONE logpost per proposal.  An iteration's random numbers --
+# u <- runif(1) and the innovation rnorm(q) %*% chol(sqrt(2) V) that mnormt::rmnorm(1, theta.old, sqrt(2) V) adds to theta.old
+# -- do not depend on whether the previous proposal was accepted, so a block of m iterations is pre-drawn in the script's
+# order (runif(1), rnorm(q), runif(1), rnorm(q), ...), the 2^m - 1 candidates the chain can reach are evaluated in one device
+# call and the accept / reject decisions are read off (r/ccgp_shim.c: ccgp_R_metro_steps).  The chain, the Geweke tests between
+# iterations (coda, R code below as in the script) and the state of R's generator afterwards are those of the script's own
+# loop: where the loop ends inside a block, .Random.seed is put back to the block's start and exactly the consumed pairs are
+# drawn again.  Needs the slim frame (R.Inv per accepted draw is not formed); otherwise the script's Metro stays in place.
+.ccgp.Metro <- function(start, N, samp.size, batch.size, alpha, D.train, sigma2, y, prior, logpost.one, ...) {
+  pb <- txtProgressBar(min = 0, max = N, style = 3)
+  est <- laplace(function(theta) logpost.one(theta)$val, start, ...)        # GV / ISO / ANI / BSQ hand `...` on to laplace
+  U <- chol(sqrt(2) * est$var)                       # rmnorm's own factor: candidate = mean + rnorm(q) %*% chol(varcov)
+  q <- length(start)
+  samp <- matrix(0, ncol = q, nrow = N)
+  beta <- list(); R.Inv <- list(); log.posterior <- list()
+  theta.old <- as.vector(est$mode)
+  l.old <- logpost.one(theta.old)
+  state <- c(l.old$val, l.old$beta)
+  k <- 1; pv <- 0
+  X <- .ccgp.mat(D.train); yy <- as.double(y)
+  while (k <= N & pv < alpha) {
+    m <- as.integer(ccgp.metro.block)
+    if (!exists(".Random.seed", envir = .GlobalEnv)) runif(1)
+    seed0 <- get(".Random.seed", envir = .GlobalEnv)
+    u <- numeric(m); E <- matrix(0, m, q)
+    for (t in 1:m) { u[t] <- runif(1); E[t, ] <- drop(matrix(rnorm(q), 1, q) %*% U) }
+    r <- .Call("ccgp_R_metro_steps", X, yy, as.double(sigma2), as.double(prior), as.double(theta.old), as.double(state), u, E)
+    used <- 0L
+    for (t in 1:m) {
+      if (!(k <= N & pv < alpha)) break
+      used <- used + 1L
+      if (r$accepted[t]) {
+        theta.old <- r$theta[t, ]
+        samp[k, ] <- theta.old
+        beta <- c(beta, r$beta[t]); R.Inv <- c(R.Inv, list(0))      # slim frame: the 1 x 1 placeholder (HX:520 stores R.Inv)
+        log.posterior <- c(log.posterior, r$val[t])                 # BSQ:510 keeps the accepted values as well
+        state <- c(r$val[t], r$beta[t])
+        k <- k + 1
+        setTxtProgressBar(pb, k)
+      }
+      if ((k - 1) >= samp.size & (k - 1) %% batch.size == 0) {      # HX:526-533, unchanged
+        options(warn = 2)
+        pv <- try(min(2 * (1 - pnorm(abs(geweke.diag(mcmc(samp[(k - samp.size):(k - 1)]))$z)))), silent = TRUE)
+        if (inherits(pv, "try-error")) pv <- 0
+      }
+    }
+    if (used < m) {                                  # the loop ended inside the block: R's generator as the script leaves it
+      assign(".Random.seed", seed0, envir = .GlobalEnv)
+      for (t in seq_len(used)) { runif(1); rnorm(q) }
+    }
+  }
+  close(pb)
+  list(sample = data.frame(samp[(k - samp.size):(k - 1), ]), beta = beta[(k - samp.size):(k - 1)],
+       R.Inv = R.Inv[(k - samp.size):(k - 1)], logpost = log.posterior[(k - samp.size):(k - 1)])    # `logpost`: BSQ:529 only
+}
+if (ccgp.slim.frame && ccgp.metro.block > 1 && !(ccgp.script %in% c("D1", "D1F"))) {
+  if (ccgp.script %in% c("HX", "ADV")) {
+    Metro <- function(start, N, samp.size, batch.size, alpha, D.train, sigma2, y, theta1.pars, theta2.pars)
+      .ccgp.Metro(start, N, samp.size, batch.size, alpha, D.train, sigma2, y,
+                  c(.ccgp.prior, theta1.pars[1:2], theta2.pars[1:2]),
+                  function(theta) logpost(D.train, theta, y, sigma2, theta1.pars, theta2.pars))
+  } else {
+    Metro <- function(start, N, samp.size, batch.size, alpha, D.train, sigma2, y, ...)
+      .ccgp.Metro(start, N, samp.size, batch.size, alpha, D.train, sigma2, y, .ccgp.prior,
+                  function(theta) logpost(D.train, theta, y, sigma2), ...)
+  }
 }
 
 # ---- the prediction phase as one device call -----------------------------------------------------------------

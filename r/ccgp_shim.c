@@ -21,6 +21,7 @@
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -150,6 +151,91 @@ SEXP ccgp_R_logpost(SEXP X, SEXP theta_t, SEXP y, SEXP sigma2, SEXP prior_id, SE
   SET_VECTOR_ELT(out, 3, Rf_ScalarReal(ll));
   Rf_setAttrib(out, R_NamesSymbol, names);
   UNPROTECT(3);
+  return out;
+}
+
+/* The next m iterations of Metro's loop (HX:505-535 and its per-script copies) in ONE device call.
+ * An iteration draws u <- runif(1) and theta.candidate <- rmnorm(1, theta.old, sqrt(2) V) = theta.old + e with
+ * e = rnorm(q) %*% chol(sqrt(2) V): neither depends on whether the previous proposal was accepted, so R pre-draws m pairs
+ * (u_t, e_t) in the script's order and every state the chain can be in after t proposals is theta.old plus a subset sum of
+ * e_1 .. e_t.  The 2^m - 1 candidates are evaluated as one batch (ccgp_logpost_batch: the values the one-at-a-time logpost
+ * would return, bit for bit) and the accept / reject walk `l.cand$val - l.old$val > log(u)` (HX:510-512) only reads them.
+ *   prior = c(prior id, the script's prior parameters if it passes any), theta_old q, state_old = c(l.old$val, l.old$beta),
+ *   u m, E m x q (row t = e_t)
+ *   -> list(accepted logical m, theta m x q (state AFTER proposal t), val m (its value), beta m (its beta),
+ *           cand.val m (the candidate's value: NA where its factorisation failed -- the reference's `if (NA > ...)` would stop
+ *           the script; here such a proposal is rejected), evaluated = 2^m - 1)
+ * Geweke's test between the iterations stays R code (r/ccgp.R walks the returned path). */
+SEXP ccgp_R_metro_steps(SEXP X, SEXP y, SEXP sigma2, SEXP prior, SEXP theta_old, SEXP state_old, SEXP u, SEXP E) {
+  const int n = Rf_nrows(X), d = Rf_ncols(X), q = Rf_length(theta_old), m = Rf_length(u);
+  if (m < 1 || m > 10 || q < 3 || q > 4 || Rf_nrows(E) != m || Rf_ncols(E) != q || Rf_length(state_old) != 2 || Rf_length(prior) < 1)
+    Rf_error("ccgp_R_metro_steps: u has %d entries (1 .. 10), theta.old %d (3 or 4), E must be %d x %d", m, q, m, q);
+  const int B = (1 << m) - 1;
+  double* cand = (double*)R_alloc((size_t)B * q, sizeof(double));        /* B x q column-major */
+  double* states = (double*)R_alloc((size_t)(1 << m) * q, sizeof(double)); /* level t: 2^t states, history index = bits */
+  double* val = (double*)R_alloc(B, sizeof(double));
+  double* bet = (double*)R_alloc(B, sizeof(double));
+  int* st = (int*)R_alloc(B, sizeof(int));
+  const double* e = REAL(E);
+  for (int k = 0; k < q; ++k) states[k] = REAL(theta_old)[k];
+  int off = 0;
+  for (int t = 0; t < m; ++t) {
+    const int ns = 1 << t;
+    /* candidates of level t, then the states of level t + 1: index 2 i = rejected (state i), 2 i + 1 = accepted (candidate i);
+     * filled from the back so that the states are expanded in place */
+    for (int i = ns - 1; i >= 0; --i)
+      for (int k = 0; k < q; ++k) {
+        const double s0 = states[(size_t)i * q + k];
+        const double c = s0 + e[t + (size_t)k * m];
+        cand[(off + i) + (size_t)k * B] = c;
+        states[(size_t)(2 * i) * q + k] = s0;
+        states[(size_t)(2 * i + 1) * q + k] = c;
+      }
+    off += ns;
+  }
+  const double* pp = Rf_length(prior) > 1 ? REAL(prior) + 1 : NULL;
+  const int rc = ccgp_logpost_batch(handle(), REAL(X), n, d, REAL(y), Rf_asReal(sigma2), (int)REAL(prior)[0], cand, B, pp,
+                                    val, bet, NULL, st);
+  warn_rc(rc);
+  SEXP acc = PROTECT(Rf_allocVector(LGLSXP, m));
+  SEXP th = PROTECT(Rf_allocMatrix(REALSXP, m, q));
+  SEXP vv = PROTECT(Rf_allocVector(REALSXP, m));
+  SEXP bb = PROTECT(Rf_allocVector(REALSXP, m));
+  SEXP cv = PROTECT(Rf_allocVector(REALSXP, m));
+  double lo = REAL(state_old)[0], bo = REAL(state_old)[1];
+  double cur[4];
+  for (int k = 0; k < q; ++k) cur[k] = REAL(theta_old)[k];
+  int idx = 0;
+  off = 0;
+  for (int t = 0; t < m; ++t) {
+    const int c = off + idx;
+    const double vc = (rc < 0 || st[c] != 0 || ISNAN(val[c])) ? NA_REAL : val[c];
+    const int a = !ISNAN(vc) && (vc - lo) > log(REAL(u)[t]);
+    if (a) {
+      lo = vc;
+      bo = bet[c];
+      for (int k = 0; k < q; ++k) cur[k] = cand[c + (size_t)k * B];
+    }
+    LOGICAL(acc)[t] = a;
+    REAL(cv)[t] = vc;
+    REAL(vv)[t] = lo;
+    REAL(bb)[t] = bo;
+    for (int k = 0; k < q; ++k) REAL(th)[t + (size_t)k * m] = cur[k];
+    off += 1 << t;
+    idx = 2 * idx + a;
+  }
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 6));
+  SEXP names = PROTECT(Rf_allocVector(STRSXP, 6));
+  const char* nm[6] = {"accepted", "theta", "val", "beta", "cand.val", "evaluated"};
+  for (int i = 0; i < 6; ++i) SET_STRING_ELT(names, i, Rf_mkChar(nm[i]));
+  SET_VECTOR_ELT(out, 0, acc);
+  SET_VECTOR_ELT(out, 1, th);
+  SET_VECTOR_ELT(out, 2, vv);
+  SET_VECTOR_ELT(out, 3, bb);
+  SET_VECTOR_ELT(out, 4, cv);
+  SET_VECTOR_ELT(out, 5, Rf_ScalarInteger(B));
+  Rf_setAttrib(out, R_NamesSymbol, names);
+  UNPROTECT(7);
   return out;
 }
 
@@ -551,6 +637,7 @@ static const R_CallMethodDef call_methods[] = {
     {"ccgp_R_mixed_corr_matrix", (DL_FUNC)&ccgp_R_mixed_corr_matrix, 3},
     {"ccgp_R_mixed_corr_cross", (DL_FUNC)&ccgp_R_mixed_corr_cross, 4},
     {"ccgp_R_logpost", (DL_FUNC)&ccgp_R_logpost, 7},
+    {"ccgp_R_metro_steps", (DL_FUNC)&ccgp_R_metro_steps, 8},
     {"ccgp_R_loglik_batch", (DL_FUNC)&ccgp_R_loglik_batch, 7},
     {"ccgp_R_grid_marginal", (DL_FUNC)&ccgp_R_grid_marginal, 8},
     {"ccgp_R_predict_batch", (DL_FUNC)&ccgp_R_predict_batch, 6},

@@ -195,6 +195,25 @@ int ccgp_logpost(ccgp_handle* h, const double* X, int n, int d, const double* y,
   if (status) *status = fail;
   return fail;
 }
+int ccgp_logpost_batch(ccgp_handle* h, const double* X, int n, int d, const double* y, double sigma2, int prior_id,
+                       const double* theta_t, int B, const double* prior_pars, double* out_val, double* out_beta, double* out_loglik,
+                       int* status) {
+  if (!h || !X || !y || !theta_t || !out_val || B < 1) return CCGP_EINVAL;
+  const int q = prior_id == CCGP_PRIOR_ANI ? 4 : 3;
+  const double s = touch(X, (size_t)n * d) + touch(y, n) + sigma2 + (prior_id == CCGP_PRIOR_INVGAMMA ? touch(prior_pars, 4) : 0.0);
+  int bad = 0;
+  for (int b = 0; b < B; ++b) {
+    double t = 0.0;
+    for (int k = 0; k < q; ++k) t += theta_t[b + (size_t)k * B];
+    const int fail = theta_t[b] < -700.0;
+    out_val[b] = fail ? NAN : -(t * t) + 1e-9 * s;        /* a peaked "posterior": some proposals accepted, some not */
+    if (out_beta) out_beta[b] = t;
+    if (out_loglik) out_loglik[b] = t + 2;
+    if (status) status[b] = fail;
+    bad += fail;
+  }
+  return bad;
+}
 int ccgp_mixed_logdet_designs(ccgp_handle* h, const double* Xs, int n, int d, int B, int K, const double* params, double* out_logdet,
                               int* status) {
   if (!h || !Xs || !params || !out_logdet || B < 1) return CCGP_EINVAL;

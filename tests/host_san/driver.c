@@ -194,6 +194,19 @@ static void shim_scenarios(void) {
   a[1] = rmock_real(tt, 3, -1, 0); a[4] = rmock_int(&one_i, 1); a[5] = rmock_nil(); a[6] = rmock_int(&one_i, 1);
   r = call("ccgp_R_logpost", 7, a);
   CHECK(r && rmock_is_na_real(reals(rmock_elt(r, 0))[0]) && rmock_length(rmock_elt(r, 2)) == 1, "failed logpost -> NA, R.Inv <- NA");
+  {   /* speculative block of Metro: 2^5 - 1 candidates, R_alloc scratch, one failing candidate */
+    double th0[3] = {0.1, -0.2, 0.3}, st0[2] = {-0.5, 1.0}, uu[5] = {0.9, 0.2, 0.6, 0.05, 0.5}, pr[5] = {0, 7, 3, 3, 28};
+    double* EE = filled(5 * 3, 0.07);
+    EE[2] = -900.0;                                                  /* proposal 3 of every history: factorisation "fails" */
+    a[0] = rmock_real(X, N * D, N, D); a[1] = rmock_real(y, N, -1, 0); a[2] = rmock_real(&s2, 1, -1, 0); a[3] = rmock_real(pr, 5, -1, 0);
+    a[4] = rmock_real(th0, 3, -1, 0); a[5] = rmock_real(st0, 2, -1, 0); a[6] = rmock_real(uu, 5, -1, 0); a[7] = rmock_real(EE, 15, 5, 3);
+    r = call("ccgp_R_metro_steps", 8, a);
+    CHECK(r && rmock_length(r) == 6 && rmock_length(rmock_elt(r, 1)) == 15 && rmock_is_na_real(reals(rmock_elt(r, 4))[2]), "metro steps");
+    a[6] = rmock_real(uu, 0, -1, 0);
+    r = rmock_dot_call("ccgp_R_metro_steps", 8, a);                   /* m = 0: Rf_error, not a crash */
+    CHECK(!r, "metro steps refuses an empty block");
+    free(EE);
+  }
   const int B = 11;
   double* params = filled((size_t)B * P, 0.5);
   params[4] = -1.0;

@@ -5,4 +5,5 @@
 typedef enum { FALSE = 0, TRUE } Rboolean;
 void Rf_error(const char* fmt, ...) __attribute__((noreturn));
 void Rf_warning(const char* fmt, ...);
+char* R_alloc(size_t n, int size);
 #endif

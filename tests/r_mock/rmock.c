@@ -86,6 +86,14 @@ static SEXP new_obj(int type, R_xlen_t n) {
 
 SEXP Rf_allocVector(unsigned int type, R_xlen_t n) { return new_obj((int)type, n); }
 
+/* R_alloc: transient storage that R reclaims when the .Call returns (no PROTECT needed, never a GC hazard); here an owned
+ * byte object freed with everything else at rmock_reset */
+char* R_alloc(size_t n, int size) {
+  SEXP o = new_obj(CHARSXP, (R_xlen_t)(n * (size_t)size) + 16);
+  o->owned = 1;
+  return (char*)o->data;
+}
+
 SEXP Rf_allocMatrix(unsigned int type, int nrow, int ncol) {
   SEXP o = new_obj((int)type, (R_xlen_t)nrow * ncol);
   /* R protects the matrix while it allocates the dim vector; mirror that so allocMatrix itself is no hazard */

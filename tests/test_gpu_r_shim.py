@@ -448,3 +448,71 @@ def test_batched_routines_at_random_shapes_including_the_blocked_path(R, handle,
     want_ld, _ = handle.mixed_logdet_designs(designs, 2, P[0])
     assert np.array_equal(got, want_ld)
     assert R.warnings() == []
+
+
+# ------------------------------------------------------------------------------- Metro on the batched path
+@pytest.mark.parametrize("script,prior,q", [("GV", 1, 3), ("HX", 0, 3), ("ANI", 3, 4)])
+def test_metro_steps_is_the_sequential_chain(R, handle, script, prior, q):
+    """ccgp_R_metro_steps (the next m iterations of Metro's loop, HX:505-535, as ONE device call) against the chain the
+    script runs: one logpost per proposal (Handle.logpost = ccgp_logpost), accept on l.cand - l.old > log(u).  Same
+    pre-drawn (u, innovation) pairs for both: accepted flags, states, values and betas must agree BIT FOR BIT over 48
+    proposals in blocks of m = 1, 3, 4 and 6 -- and with the tree walk of fit.Metro(speculate = m), which reads the same
+    ccgp_logpost_batch values."""
+    from ccgp_amd import api
+    rng = np.random.default_rng(2014 + prior)
+    if script == "GV":
+        D, y, _, _ = load_gv(50, 1)
+        start, s2, pars = np.array([np.log(0.3), np.log(15.0), 0.8]), 10.25, None
+    elif script == "HX":
+        D, y, _, _ = load_qian()
+        start, s2, pars = np.array([np.log(0.3), np.log(15.0), 0.8]), 64.0, np.array([7.0, 3.0, 3.0, 28.0])
+    else:
+        D = load_maximin(100)[:60]
+        y = (np.sin(2 * D[:, 0]) + np.cos(4 * D[:, 0])) * (np.sin(8 * D[:, 1]) + np.cos(4 * D[:, 1]))
+        start, s2, pars = np.array([np.log(2.0), np.log(3.0), 0.5, np.log(4.0)]), float(np.var(y, ddof=1)), None
+    U = np.linalg.cholesky(np.diag(np.full(q, 0.25)) + 0.02).T        # any proposal factor: chol(sqrt(2) V) in the script
+    T = 48
+    u = rng.random(T)
+    E = rng.normal(size=(T, q)) @ U
+    E[17] = 60.0                                                       # one proposal far outside: exp() overflow -> NaN / reject
+
+    def one(theta):
+        r = handle.logpost(D, y, s2, prior, theta, pars, want_Rinv=False)
+        return (r["val"] if r["status"] == 0 else np.nan), r["beta"]
+
+    # the script's loop, one logpost per proposal
+    th, (lo, bo) = start.copy(), one(start)
+    seq = []
+    for t in range(T):
+        cand = th + E[t]
+        vc, bc = one(cand)
+        a = bool(np.isfinite(vc) and (vc - lo) > np.log(u[t]))
+        if a:
+            th, lo, bo = cand, vc, bc
+        seq.append((a, th.copy(), lo, bo))
+    assert 5 < sum(s[0] for s in seq) < T - 5                          # a chain that both accepts and rejects
+
+    prior_vec = np.concatenate([[float(prior)], pars]) if pars is not None else np.array([float(prior)])
+    for m in (1, 3, 4, 6):
+        th, (lo, bo) = start.copy(), one(start)
+        t = 0
+        while t < T:
+            mm = min(m, T - t)
+            r = R.dot_call("ccgp_R_metro_steps", R.real(D), R.real(y), R.real(np.array([s2])), R.real(prior_vec), R.real(th),
+                           R.real(np.array([lo, bo])), R.real(u[t:t + mm]), R.real(E[t:t + mm].reshape(mm, q)))
+            acc, theta, val, beta, nev = r["accepted"], r["theta"], r["val"], r["beta"], r["evaluated"]
+            assert int(np.ravel(nev)[0]) == 2 ** mm - 1
+            for i in range(mm):
+                a, th_s, lo_s, bo_s = seq[t + i]
+                assert bool(acc[i]) == a, (m, t + i)
+                assert np.array_equal(np.atleast_2d(theta)[i], th_s) and val[i] == lo_s and beta[i] == bo_s, (m, t + i)
+            th, lo, bo = np.atleast_2d(theta)[mm - 1].copy(), float(val[mm - 1]), float(beta[mm - 1])
+            t += mm
+        assert R.warnings() == [] or all("libccgp" not in w for w in R.warnings())
+    assert R.is_na(np.atleast_1d(R.dot_call("ccgp_R_metro_steps", R.real(D), R.real(y), R.real(np.array([s2])), R.real(prior_vec),
+                                            R.real(start), R.real(np.array(one(start))), R.real(u[17:18]),
+                                            R.real(E[17:18].reshape(1, q)))["cand.val"]))[0]
+
+    # the same values through the Python host layer's batch (fit.logpost_batch -> ccgp_logpost_batch)
+    vb, bb, _, _ = handle.logpost_batch(D, y, s2, prior, np.stack([start + E[0], start + E[1]]), pars)
+    assert vb[0] == one(start + E[0])[0] and bb[1] == one(start + E[1])[1]

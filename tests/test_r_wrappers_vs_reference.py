@@ -149,3 +149,36 @@ def test_overridden_signatures_match(tag):
     assert f == ["MCMC.data", "n.train", "y.train"]
     f, _ = definition(src, "predict.post")
     assert f[:4] == ["x.new", "D.train", "pars", "sigma2"]
+
+
+@pytest.mark.parametrize("tag", ["HX", "GV", "ISO", "ADV", "ANI", "BSQ"])
+def test_metro_loop_is_what_the_block_wise_metro_assumes(rsrc, tag):
+    """r/ccgp.R's Metro pre-draws m iterations' random numbers.  That is the script's chain only if the script's loop draws
+    exactly  u <- runif(1)  and then  rmnorm(1, as.vector(theta.old), sqrt(2)*pars$v)  per iteration, in this order, accepts on
+    R > log(u) with R = l.cand$val - l.old$val, and runs Geweke's test on the first column of the last samp.size accepted draws
+    whenever (k-1) >= samp.size & (k-1) %% batch.size == 0 -- and if every call site passes Metro's arguments by position."""
+    src = script(tag)
+    formals, body = definition(src, "Metro")
+    flat = re.sub(r"\s+", "", body)
+    assert formals[:8] == ["start", "N", "samp.size", "batch.size", "alpha", "D.train", "sigma2", "y"]
+    assert len(formals) == (10 if tag in ("HX", "ADV") else 9), formals
+    i_u, i_c = flat.index("u<-runif(1)"), flat.index("theta.candidate<-rmnorm(1,as.vector(theta.old),sqrt(2)*pars$v)")
+    assert 0 < i_u < i_c and flat.count("runif(") == 1 and flat.count("rmnorm(") == 1 and "rnorm(" not in flat.replace("rmnorm(", "")
+    assert "R<-l.cand$val-l.old$val" in flat and "if(R>log(u))" in flat
+    assert "while(k<=N&pv<alpha)" in flat
+    assert "if((k-1)>=samp.size&(k-1)%%batch.size==0)" in flat
+    assert "geweke.diag(mcmc(samp[(k-samp.size):(k-1)]))$z" in flat
+    assert ("est<-laplace(logpost.val,start)" in flat or "est<-laplace(logpost.val,start,...)" in flat) and "pars<-list(mu=est$mode,v=est$var)" in flat
+    assert "theta.old<-pars$mu" in flat and "k=1" in flat
+    tail = "R.Inv=R.Inv[(k-samp.size):(k-1)]" + (",logpost=log.posterior[(k-samp.size):(k-1)]" if tag == "BSQ" else "") + "))"
+    assert flat.rstrip("}").endswith(tail)        # the list r/ccgp.R's Metro returns (it always adds BSQ's `logpost`)
+    assert "logpost = log.posterior[(k - samp.size):(k - 1)]" in open(os.path.join(ROOT, "r", "ccgp.R")).read()
+    # every call of Metro in the script passes its arguments by position
+    for m in re.finditer(r"\bMetro\s*\(([^)]*)\)", src):
+        if "function" in src[max(0, m.start() - 12):m.start()]:
+            continue
+        assert "=" not in m.group(1), m.group(0)
+    # r/ccgp.R's replacement takes the same number of arguments
+    r_formals = re.search(r"Metro <- function\(([^)]*)\)\s*\n\s*\.ccgp\.Metro\(start, N, samp\.size, batch\.size, alpha, D\.train, sigma2, y,\s*\n\s*c\(\.ccgp\.prior",
+                          open(os.path.join(ROOT, "r", "ccgp.R")).read())
+    assert r_formals and len(r_formals.group(1).split(",")) == 10

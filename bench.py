@@ -979,7 +979,58 @@ def secondary_items(c, h, sec_in, cpu_sec, X, y, P, K, sigma2):
             item["rel_dev_from_cpu_central_differences_max"] = float(
                 np.max(np.abs(gg[0] - fd) / (np.abs(fd) + 1e-3 * np.abs(fd).max())))
         items.append(item)
+    items.append(end_to_end_fit_item(h))
     return items
+
+
+def end_to_end_fit_item(h):
+    """The whole fit of the Ground-Vibrations script on training sample 1 (GV driver block GV:688-695: start c(1,1,0), N.max
+    5000, samp.size 1000, alpha.geweke 0.5, batch 20; sigma2 given) -- laplace + Metro + the 1000-draw x 150-site prediction
+    tables -- with the sampler one logpost per proposal (the script's loop) and with blocks of m = 4 proposals per device call
+    (fit.Metro(speculate = 4) = what r/ccgp.R's Metro does through ccgp_R_metro_steps).  Same seed: the two chains must be the
+    same chain."""
+    import ccgp_amd  # noqa: F401
+    from ccgp_amd import fit
+    from ccgp_amd.rsurface import CombinedGP
+    from ccgp_amd.tables import read_table
+    data = os.path.join(ROOT, "tests", "golden", "data", "gv")
+    _, tr = read_table(os.path.join(data, "train_50_1.txt"))
+    _, te = read_table(os.path.join(data, "test_50_1.txt"))
+    D, y, Dt, yt = tr[:, :9], tr[:, 9], te[:, :9], te[:, 9]
+    gp = CombinedGP("GV", handle=h)
+    out = {"workload": "end-to-end fit: Ground Vibrations sample 1 (n = 50, d = 9): laplace + Metro (1000 retained draws, Geweke "
+                       "stopping rule) + prediction at 150 sites, sigma2 = 10.2494 (the value behind the reference's recorded table)"}
+    runs = {}
+    for name, m in (("sequential", 0), ("blocks_of_4", 4)):
+        calls = {"logpost": 0, "rows": 0, "s": 0.0}
+        inner = fit.logpost_batch
+
+        def counted(gp_, D_, rows, y_, s2_, pars_=None):
+            t0 = time.perf_counter()
+            r = inner(gp_, D_, rows, y_, s2_, pars_)
+            calls["s"] += time.perf_counter() - t0
+            calls["logpost"] += 1
+            calls["rows"] += np.atleast_2d(rows).shape[0]
+            return r
+        fit.logpost_batch = counted
+        try:
+            t0 = time.perf_counter()
+            table = fit.Combined_GP_fit(gp, D, y, Dt, [1.0, 1.0, 0.0], 5000, 1000, 0.5, 20, alpha=0.05, y_new=yt, sigma2=10.2494,
+                                        rng=20140101, speculate=m)
+            el = time.perf_counter() - t0
+        finally:
+            fit.logpost_batch = inner
+        ch = table["chain"]
+        runs[name] = {"seconds_per_fit": el, "device_calls": calls["logpost"], "candidates_evaluated": calls["rows"],
+                      "seconds_in_device_calls": calls["s"], "host_share": 1.0 - calls["s"] / el,
+                      "proposals": ch["proposals"], "accepted": ch["accepted"], "rmspe": fit.comparison_summary(table)["rmspe"]}
+        runs[name + "_draws"] = table["draws"]
+    out["same_chain"] = bool(np.array_equal(runs.pop("sequential_draws"), runs.pop("blocks_of_4_draws")))
+    out.update(runs)
+    out["note"] = ("device_calls counts laplace's (one candidate each: Nelder-Mead and the Hessian stencil) and the sampler's; "
+                   "host_share = Python host layer (Geweke test, accept / reject walk, prediction summaries) and is what an R host "
+                   "would spend in R")
+    return out
 
 
 def cfg4_predict_sites(d):

@@ -19,7 +19,7 @@ PRIOR_INVGAMMA, PRIOR_GV, PRIOR_ISO, PRIOR_ANI = 0, 1, 2, 3
 T_COV, T_UPDATE, T_DIAG, T_TRSM, T_SOLVE, T_FUSED = range(6)
 KERNEL_GAUSS, KERNEL_MATERN, KERNEL_MATERN_SPLINE = 0, 1, 2
 OPT_FUSE_DIAG, OPT_TAIL_STRIPS, OPT_WIDE_OFFSETS, OPT_SMALL_GRID16 = 2, 3, 4, 5
-OPT_SCHED, OPT_SCHED_POLICY = 7, 8
+OPT_SCHED, OPT_SCHED_POLICY, OPT_PREDICT_FACTOR = 7, 8, 9
 TIMING_NAMES = ("cov", "update", "diag", "trsm", "solve", "fused", "sweep")
 
 _dp = POINTER(c_double)

@@ -534,6 +534,9 @@ int ccgp_destroy(ccgp_handle* h) try {
   if (h->pin) (void)hipHostFree(h->pin);
   for (auto& e : h->pull_ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
+  if (h->aux_join) (void)hipEventDestroy(h->aux_join);
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return CCGP_OK;
@@ -583,6 +586,10 @@ int ccgp_set_option(ccgp_handle* h, int option, int value) try {
   }
   if (option == CCGP_OPT_SMALL_GRID16 && (value == 0 || value == 1)) {
     h->opt_small_grid16 = value;
+    return CCGP_OK;
+  }
+  if (option == CCGP_OPT_PREDICT_FACTOR && (value == 0 || value == 1)) {
+    h->opt_predict_factor = value;
     return CCGP_OK;
   }
   if (option == CCGP_OPT_SCHED && value >= 0 && value <= 3) {
@@ -1415,10 +1422,27 @@ int ccgp_predict_batch_dev(ccgp_handle* h, const double* dX, int n, int d, const
   }
   {
     ScopedTimer t(h, CCGP_T_FUSED);
-    if (small_reg_supported(n, d, K, false, true))
+    if (small_reg_supported(n, d, K, false, true)) {
+      // kept-factor scheme where it applies (n <= 104, K <= 3) and its scratch fits the workspace: the factor block and the
+      // correlation vectors of as many draws at a time as the limit allows (at least 64)
+      void* scratch = nullptr;
+      size_t sbytes = 0;
+      if (h->opt_predict_factor && small_reg_sites_supported(n, d, K)) {
+        const size_t per = small_reg_sites_scratch(n, d, K, m);
+        const size_t want = per * (size_t)S, cap = std::max<size_t>(h->ws_limit / 2, per * 64);
+        if (ensure_ws(h, std::min(want, cap / per * per)) == CCGP_OK) { scratch = h->ws; sbytes = h->ws_bytes; }
+        if (scratch && !h->aux_stream) {
+          if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) h->aux_stream = nullptr;
+          if (h->aux_stream && (hipEventCreateWithFlags(&h->aux_fork, hipEventDisableTiming) != hipSuccess ||
+                                hipEventCreateWithFlags(&h->aux_join, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipStreamDestroy(h->aux_stream);
+            h->aux_stream = nullptr;
+          }
+        }
+      }
       launch_small_reg_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
-                               d_status);
-    else
+                               d_status, scratch, sbytes, h->aux_stream, h->aux_fork, h->aux_join);
+    } else
       launch_small_predict(h->stream, dX, n, d, dy, dv, S, dXtest, m, sigma2, d_mean, d_var, d_beta,
                            d_status);
   }

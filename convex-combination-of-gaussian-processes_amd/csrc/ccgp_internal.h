@@ -67,6 +67,7 @@ struct ccgp_handle {
   hipStream_t stream = nullptr;
   size_t ws_limit = size_t(24) << 30;   // ccgp_create replaces this by 3/4 of the device's memory
   int opt_small_grid16 = 0;             // CCGP_OPT_SMALL_GRID16
+  int opt_predict_factor = 1;           // CCGP_OPT_PREDICT_FACTOR
   int opt_fuse_diag = 1;                // CCGP_OPT_FUSE_DIAG
   int opt_tail_strips = 1;              // CCGP_OPT_TAIL_STRIPS
   int opt_wide_offsets = 0;             // CCGP_OPT_WIDE_OFFSETS
@@ -87,6 +88,8 @@ struct ccgp_handle {
   void* pin = nullptr;
   size_t pin_bytes = 0;
   size_t pin_in = 0;     // bytes of `pin` holding the inputs of the call in flight (results land behind them)
+  hipStream_t aux_stream = nullptr;     // second stream of the kept-factor prediction (created on first use)
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   hipEvent_t pull_ev[ccgp::kPullSlices] = {};   // one per slice of a large result on its way back (capi.hip: pull)
   std::string err;
   ccgp::KernelFamily fam;
@@ -146,7 +149,10 @@ void launch_small_grad(hipStream_t s, const double* X, int n, int d, const doubl
 bool small_reg_supported(int n, int d, int K, bool per_design = false, bool predict = false);
 void launch_small_reg_predict(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                               int S, const double* Xtest, int m, double sigma2, double* mean, double* var,
-                              double* beta, int* status);
+                              double* beta, int* status, void* scratch = nullptr, size_t scratch_bytes = 0,
+                              hipStream_t aux = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
+bool small_reg_sites_supported(int n, int d, int K);          // kept-factor prediction (round 5): n <= 104, K <= 3
+size_t small_reg_sites_scratch(int n, int d, int K, int m);   // bytes of scratch per draw it needs
 void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int d, DrawView dv, int B,
                                      double* logdet, int* status);
 // solve(R) of ONE draw (logpost with R.Inv, HX:454) on the register-resident scheme; likelihood and beta of the same

@@ -24,6 +24,7 @@
 //
 // Bound: neither HBM nor MFMA -- n dependent elimination steps; algorithmic HBM traffic per
 // evaluation is the parameter row in (8 P bytes) and 20 bytes out.
+#include <algorithm>
 #include <type_traits>
 
 #include "ccgp_internal.h"
@@ -59,6 +60,30 @@ struct RegArgs {
   double* grad;        // INV = 2: d loglik / d params, Btot x P column-major (element (b, j) at grad[b + j * Btot])
   int Btot;
   int grid16;          // CCGP_OPT_SMALL_GRID16: 64 < n <= 104 on the 16 x 16 grid (measurements)
+  double* fac;         // FAC instantiation: per draw a block of fac_stride doubles that keeps the factor for predict_sites_kernel
+  size_t fac_stride;
+};
+
+// ---- the factor a prediction keeps (round 5) ------------------------------------------------------------------------
+// Rounds 2 - 4 predicted by carrying the cross-correlation rows of a CHUNK of test sites (30 at n <= 64, 62 above) through the
+// elimination as extra rows, one workgroup per (draw, chunk): every chunk generated and factorised the draw's matrix again --
+// five times for the 150 sites of a Ground-Vibrations test set.  Now the likelihood instantiation (NE = 1, FAC) factorises
+// ONCE per draw and writes L' (unit lower), 1 / d, z'_y, z'_1, beta and 1'R^-1 1 to a block in HBM (11 KB at n = 50); beside it
+// -- on a second stream, it needs nothing from the factorisation -- site_corr_kernel forms the test sites' correlation vectors
+// r(x_t) with lane = test site; site_solve_kernel then does the forward substitution w' = L'^-1 r and predict.post's arithmetic,
+// again lane = site, every matrix operand a broadcast LDS read.  Same operations in the same order per (draw, site) as the
+// extra-row scheme, hence the same bits.
+//   hdr[8]: beta, s11, bad, sw | rd[NPF] | zy[NPF] | z1[NPF] | L'
+// L' in HBM: column-major packed (column k = rows k + 1 .. n - 1, contiguous: the elimination writes a column per step,
+// coalesced); predict_sites_kernel re-lays it in LDS by row blocks of eight (lrect / ltri below).
+__host__ __device__ constexpr int fac_npf(int n) { return (n + 7) / 8 * 8; }
+__host__ __device__ constexpr int fac_col(int n, int k) { return k * (n - 1) - k * (k - 1) / 2; }   // first entry (row k + 1) of column k
+struct FacLayout {
+  int npf, rd, zy, z1, L, head, total;
+  __host__ __device__ FacLayout(int n) {
+    npf = fac_npf(n);
+    rd = 8; zy = rd + npf; z1 = zy + npf; L = z1 + npf; head = L; total = (L + n * (n - 1) / 2 + 7) / 8 * 8;
+  }
 };
 
 // doubles of LDS per matrix, from the ACTUAL number of components and dimensions (round 3: sized for kMaxK / kMaxD
@@ -100,14 +125,18 @@ __device__ __forceinline__ void mat_sync() {
 #ifndef CCGP_SMALL_OCC_G16
 #define CCGP_SMALL_OCC_G16 4
 #endif
+#ifndef CCGP_FAC_WIDE_MAX
+#define CCGP_FAC_WIDE_MAX 64
+#endif
 #ifndef CCGP_SMALL_OCC_PRED
 #define CCGP_SMALL_OCC_PRED 3
 #endif
 // INV: 0 = none, 1 = explicit inverse (solve(R), HX:454), 2 = analytic gradient of the profile-beta log-likelihood
-template <int G, int NB, int NE, bool FULL = false, int INV = 0>
+template <int G, int NB, int NE, bool FULL = false, int INV = 0, bool FAC = false>
 __global__ __launch_bounds__(256, INV ? 1 : (NE > 1 ? CCGP_SMALL_OCC_PRED : (G == 8 ? (NB > 8 ? 2 : CCGP_SMALL_OCC_G8) : CCGP_SMALL_OCC_G16)))
 void small_reg_kernel(RegArgs a) {
   static_assert(!INV || (G == 16 && NE == NB + 1 && !FULL), "the inverse / gradient runs one matrix per workgroup with n identity rows");
+  static_assert(!FAC || (NE == 1 && !FULL && !INV), "the factor is kept by the plain likelihood instantiation");
   constexpr int TPM = G * G;       // threads per matrix
   constexpr int MPW = 256 / TPM;   // matrices per workgroup
   constexpr int NP = G * NB;       // padded order
@@ -316,6 +345,13 @@ void small_reg_kernel(RegArgs a) {
       rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
       rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
       if (lt == 0) dvec[k] = piv;
+      if constexpr (FAC) {
+        // column k of L' (the values every thread forms as lc below), into the row-major packed factor: entry (i, k) of row i
+        if (valid) {
+          double* Lp = a.fac + (size_t)b * a.fac_stride + FacLayout(n).L + fac_col(n, k) - (k + 1);
+          for (int i = k + 1 + lt; i < n; i += TPM) Lp[i] = cb[i] * rinv;
+        }
+      }
       double lc[NB], lr[NB];
 #pragma unroll
       for (int bb = kb; bb < NB; ++bb) lc[bb] = cb[tx + G * bb] * rinv;
@@ -394,6 +430,18 @@ void small_reg_kernel(RegArgs a) {
     if (lt == 0) {
       zb[2 * NP] = beta;      // for the prediction epilogue (slack words behind zb)
       zb[2 * NP + 1] = s11;
+    }
+    if constexpr (FAC) {
+      if (valid) {
+        const FacLayout fl(n);
+        double* F = a.fac + (size_t)b * a.fac_stride;
+        if (lt == 0) { F[0] = beta; F[1] = s11; F[2] = bad ? 1.0 : 0.0; F[3] = sw; }
+        for (int c = lt; c < n; c += 64) {
+          F[fl.rd + c] = bad ? 0.0 : 1.0 / dvec[c];
+          F[fl.zy + c] = zb[c];
+          F[fl.z1 + c] = zb[NP + c];
+        }
+      }
     }
     if (lt == 0 && valid && blockIdx.y == 0) {
       if (a.loglik) a.loglik[b] = ll;
@@ -608,13 +656,21 @@ void launch_one(hipStream_t s, const RegArgs& a) {
     raise_lds_limit((const void*)small_reg_kernel<G, NB, NE, false>, "small_reg_kernel");
     if constexpr (NE == 1) raise_lds_limit((const void*)small_reg_kernel<G, NB, NE, true>, "small_reg_kernel<full>");
   });
-  const bool full = NE == 1 && a.n == G * NB && a.x_stride == 0;
+  const bool full = NE == 1 && a.n == G * NB && a.x_stride == 0 && !a.fac;
   const int chunks = NE > 1 ? (a.m + (G * NE - 2) - 1) / (G * NE - 2) : 1;
   const int kMaxGrid = 1 << 20;
   RegArgs c = a;
   for (int b0 = 0; b0 < a.B; b0 += kMaxGrid * MPW) {
     c.draw0 = a.draw0 + b0;
     c.B = a.B - b0 < kMaxGrid * MPW ? a.B - b0 : kMaxGrid * MPW;
+    if constexpr (NE == 1) {
+      if (a.fac) {   // the likelihood instantiation that keeps its factor for predict_sites_kernel
+        static unsigned long long fac_mask = 0;
+        once_per_device(fac_mask, [] { raise_lds_limit((const void*)small_reg_kernel<G, NB, NE, false, 0, true>, "small_reg_kernel<fac>"); });
+        hipLaunchKernelGGL((small_reg_kernel<G, NB, NE, false, 0, true>), dim3((c.B + MPW - 1) / MPW, 1), dim3(256), lds, s, c);
+        continue;
+      }
+    }
     if constexpr (NE == 1) {
       if (full) {
         hipLaunchKernelGGL((small_reg_kernel<G, NB, NE, true>), dim3((c.B + MPW - 1) / MPW, chunks), dim3(256), lds, s, c);
@@ -625,7 +681,298 @@ void launch_one(hipStream_t s, const RegArgs& a) {
   }
 }
 
+
+// ---- prediction from the kept factor: lane = test site ---------------------------------------------------------------
+struct SiteArgs {
+  const double* fac;       // ns blocks of fac_stride doubles (FacLayout)
+  size_t fac_stride;
+  const double* X;         // n x d, column-major
+  const double* params;    // draws, column-major with leading dimension ldp
+  int ldp;
+  int n, d, K;
+  const double* Xt;        // m x d, column-major
+  int m, S, draw0;         // this launch serves draws draw0 .. of the S x m tables; fac / rs are indexed from 0
+  double sigma2;
+  double* mean;
+  double* var;
+  double* rs;              // per (draw, 64-site batch) NPF x 64 doubles: the correlation vectors, lane-major
+  int nbatch, npf;         // ceil(m / 64); n rounded up to a multiple of 8
+};
+
+// r_i(x_t) = Mixed.corr.vec (HX:425-431) in corr.vec's operation order (HX:373: (theta'x^2 - 2 X Theta x) + u_i) for one draw and
+// up to four batches of 64 test sites (one wave each): the scaled training coordinates x_ik theta_qk and u_qi = sum_k theta_qk
+// x_ik^2 are formed once per workgroup in LDS and read by broadcast; a lane's site coordinates sit in LDS too ([k][lane]).
+// Needs nothing from the factorisation: runs beside it.
+template <int KC>
+__global__ __launch_bounds__(256, 4) void site_corr_kernel(SiteArgs a) {
+  constexpr int RB = 8;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, nbatch = a.nbatch, npf = a.npf;
+  const int batch = blockIdx.x * (nthr >> 6) + wave;
+  const int n = a.n, d = a.d, m = a.m, gb = a.draw0 + b;
+  double* th = smem;                                 // [KC][d]
+  double* w2 = th + (KC * d + 7) / 8 * 8;            // [8]
+  double* us = w2 + 8;                               // [KC][npf]
+  double* xs = us + KC * npf;                        // [KC][d][npf]
+  double* xw = xs + (size_t)KC * d * npf + (size_t)wave * d * 64;   // this wave's test sites, [k][lane]
+  for (int e = tid; e < KC * d; e += nthr) th[e] = a.params[gb + (size_t)(KC + e) * a.ldp];
+  if (tid < KC) { const double w = a.params[gb + (size_t)tid * a.ldp]; w2[tid] = w * w; }
+  const int t = batch * 64 + lane;
+  const int tc = t < m ? t : m - 1;                  // lanes beyond m compute a valid site; nobody reads their column
+  if (batch < nbatch)
+    for (int k = 0; k < d; ++k) xw[k * 64 + lane] = a.Xt[tc + (size_t)k * m];
+  __syncthreads();
+  for (int e = tid; e < KC * d * npf; e += nthr) {
+    const int i = e % npf, qk = e / npf;             // qk = q * d + k
+    xs[e] = i < n ? a.X[i + (size_t)(qk % d) * n] * th[qk] : 0.0;
+  }
+  for (int e = tid; e < KC * n; e += nthr) {
+    const int c = e / n, i = e % n;
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) { const double v = a.X[i + (size_t)k * n]; s += v * v * th[c * d + k]; }
+    us[c * npf + i] = s;
+  }
+  __syncthreads();
+  if (batch >= nbatch) return;
+  double sw = 0.0;
+  for (int c = 0; c < KC; ++c) sw += w2[c];
+  double* __restrict__ rs = a.rs + ((size_t)b * nbatch + batch) * npf * 64 + lane;
+  const double* xl = xw + lane;
+  double ut[KC];
+#pragma unroll
+  for (int q = 0; q < KC; ++q) {
+    double sq = 0.0;
+    for (int k = 0; k < d; ++k) { const double v = xl[k * 64]; sq += v * v * th[q * d + k]; }
+    ut[q] = sq;
+  }
+  for (int i0 = 0; i0 < n; i0 += RB) {
+    double sd[KC][RB];
+#pragma unroll
+    for (int q = 0; q < KC; ++q)
+#pragma unroll
+      for (int j = 0; j < RB; ++j) sd[q][j] = 0.0;
+    double xn = xl[0];
+    for (int k = 0; k < d; ++k) {
+      const double x = xn;
+      xn = xl[(k + 1 < d ? k + 1 : k) * 64];         // the next dimension's coordinate is under way during this one's FMAs
+#pragma unroll
+      for (int q = 0; q < KC; ++q) {
+        const d2v* xv = reinterpret_cast<const d2v*>(xs + (size_t)(q * d + k) * npf + i0);
+        const d2v v0 = xv[0], v1 = xv[1], v2 = xv[2], v3 = xv[3];
+        sd[q][0] = fma(v0[0], x, sd[q][0]); sd[q][1] = fma(v0[1], x, sd[q][1]);
+        sd[q][2] = fma(v1[0], x, sd[q][2]); sd[q][3] = fma(v1[1], x, sd[q][3]);
+        sd[q][4] = fma(v2[0], x, sd[q][4]); sd[q][5] = fma(v2[1], x, sd[q][5]);
+        sd[q][6] = fma(v3[0], x, sd[q][6]); sd[q][7] = fma(v3[1], x, sd[q][7]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      if (i0 + j < n) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < KC; ++q) {
+          const double dist = (ut[q] - 2.0 * sd[q][j]) + us[q * npf + i0 + j];
+          acc = fma(w2[q], exp_small<true>(dist, nullptr), acc);
+        }
+        rs[(size_t)(i0 + j) * 64] = acc / sw;
+      }
+    }
+  }
+}
+size_t site_corr_lds_bytes(int n, int d, int K, int waves) {
+  const int npf = fac_npf(n);
+  return sizeof(double) * ((size_t)(K * d + 7) / 8 * 8 + 8 + (size_t)K * npf + (size_t)K * d * npf + (size_t)waves * d * 64);
+}
+
+// LDS image of L' for the blocked forward substitution: row block I (rows 8 I .. 8 I + 7) holds first its rectangle -- columns
+// k < 8 I, each column as the block's 8 row entries side by side (one FMA per row and column, eight independent chains, the
+// operands of a column in four ds_read_b128) -- then its 8 x 8 triangle row by row (row j: its j entries).
+// (block I starts at sum_{J<I} (64 J + 32) = 32 I^2 words)
+__host__ __device__ constexpr int lrect(int I, int k, int j) { return 32 * I * I + k * 8 + j; }
+__host__ __device__ constexpr int ltri(int I, int j, int c) { return 32 * I * I + 64 * I + j * (j - 1) / 2 + c; }
+template <int NPF>
+constexpr size_t site_solve_lds_doubles(int n) { return (size_t)FacLayout(n).head + 32 * (NPF / 8) * (NPF / 8) + 8; }
+
+// One workgroup per (draw, group of up to four batches of 64 test sites), one wave per batch.  The draw's factor block comes
+// into LDS once per workgroup (one linear coalesced stream; L' re-laid by row blocks) and every factor operand is then a
+// broadcast LDS read.  [A first version read them through scalar loads, one SGPR operand per FMA: 153 us per Ground-Vibrations
+// set at n = 50 against 181 for the extra-row scheme -- 10 - 37 KB of L' per wave through a scalar cache that a CU's waves share
+// is a latency chain, not a stream.]  Fully unrolled so that w' lives in registers with static indices:
+// w'_i = r_i - sum_{k<i} L'_ik w'_k, one accumulator per row, ascending k as the rank-1 updates of the extra-row scheme applied
+// them; eight rows at a time: their sums over the finished columns are eight independent chains, then the block's own triangle
+// row by row.  Then the three D-weighted dot products in that scheme's summation order (per column class x = c mod GS, classes
+// in ascending order; GS = 8 for n <= 64, 16 above: the thread grids the extra rows were spread over): the bits of rounds 2 - 4.
+template <int NPF>
+__global__ __launch_bounds__(256, NPF <= 48 ? 3 : 2) void site_solve_kernel(SiteArgs a) {
+  constexpr int NBL = NPF / 8;
+  constexpr int GS = NPF <= 64 ? 8 : 16;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, nbatch = a.nbatch;
+  const int batch = blockIdx.x * (nthr >> 6) + wave;
+  const int n = a.n, m = a.m;
+  const FacLayout fl(n);
+  const double* __restrict__ Fg = a.fac + (size_t)b * a.fac_stride;
+  double* F = smem;                                  // the block's head as it is in HBM ...
+  double* L = smem + fl.head;                        // ... and L' in row blocks of 8 (lrect / ltri)
+  for (int e = tid; e < fl.head; e += nthr) F[e] = Fg[e];
+  {
+    // L' arrives as one linear, coalesced stream (four loads in flight per thread); a thread finds the column of its
+    // element by walking the column starts forward
+    const double* __restrict__ Lg = Fg + fl.L;
+    const int total = n * (n - 1) / 2;
+    int k = 0, cs = 0, len = n - 1;                  // column k holds rows k + 1 .. n - 1 at [cs, cs + len)
+    for (int e0 = tid; e0 < total; e0 += 4 * nthr) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = e0 + u * nthr < total ? Lg[e0 + u * nthr] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * nthr;
+        if (e < total) {
+          while (e >= cs + len) { cs += len; --len; ++k; }
+          const int i = k + 1 + (e - cs), I = i >> 3, j = i & 7;
+          L[k < 8 * I ? lrect(I, k, j) : ltri(I, j, k - 8 * I)] = v[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (batch >= nbatch) return;
+  const int t = batch * 64 + lane;
+  const double* __restrict__ rs = a.rs + ((size_t)b * nbatch + batch) * NPF * 64 + lane;
+
+  double w[NPF];
+  // the next row block's correlation entries are requested a block ahead where the registers allow (w alone is 2 NPF of them);
+  // the scheduling barriers keep the compiler from hoisting every block's loads to the top (1.1 KB of scratch per lane at NPF = 96)
+  constexpr bool AHEAD = NPF <= 56;
+  double nxt[8];
+  if constexpr (AHEAD) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nxt[j] = j < n ? rs[(size_t)j * 64] : 0.0;
+  }
+#pragma unroll
+  for (int I = 0; I < NBL; ++I) {
+    double acc[8];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = nxt[j];
+      if (I + 1 < NBL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nxt[j] = (8 * (I + 1) + j < n) ? rs[(size_t)(8 * (I + 1) + j) * 64] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = (8 * I + j < n) ? rs[(size_t)(8 * I + j) * 64] : 0.0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (8 * I < n) {
+      // column k + 1's four ds_read_b128 are issued before column k's eight FMAs, and no further: left alone the scheduler
+      // hoists the reads of dozens of columns and spills w
+      d2v v0, v1, v2, v3;
+      if (I > 0) {
+        const d2v* c = reinterpret_cast<const d2v*>(L + lrect(I, 0, 0));
+        v0 = c[0]; v1 = c[1]; v2 = c[2]; v3 = c[3];
+      }
+#pragma unroll
+      for (int k = 0; k < 8 * I; ++k) {
+        d2v n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+        if (k + 1 < 8 * I) {
+          const d2v* c = reinterpret_cast<const d2v*>(L + lrect(I, k + 1, 0));
+          n0 = c[0]; n1 = c[1]; n2 = c[2]; n3 = c[3];
+        }
+        const double wk = -w[k];
+        acc[0] = fma(wk, v0[0], acc[0]); acc[1] = fma(wk, v0[1], acc[1]);
+        acc[2] = fma(wk, v1[0], acc[2]); acc[3] = fma(wk, v1[1], acc[3]);
+        acc[4] = fma(wk, v2[0], acc[4]); acc[5] = fma(wk, v2[1], acc[5]);
+        acc[6] = fma(wk, v3[0], acc[6]); acc[7] = fma(wk, v3[1], acc[7]);
+        __builtin_amdgcn_sched_barrier(0);
+        v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+      }
+#pragma unroll
+      for (int j = 1; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < j; ++c) acc[j] = fma(-acc[c], L[ltri(I, j, c)], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[8 * I + j] = (8 * I + j < n) ? acc[j] : 0.0;
+  }
+
+  double ww = 0.0, z1w = 0.0, zyw = 0.0;
+#pragma unroll
+  for (int x = 0; x < GS; ++x) {
+    double pw = 0.0, p1 = 0.0, py = 0.0;
+#pragma unroll
+    for (int c = x; c < NPF; c += GS) {
+      if (c < n) {
+        const double wc = w[c], wr = wc * F[fl.rd + c];
+        pw = fma(wc, wr, pw);
+        p1 = fma(F[fl.z1 + c], wr, p1);
+        py = fma(F[fl.zy + c], wr, py);
+      }
+    }
+    ww += pw;
+    z1w += p1;
+    zyw += py;
+  }
+  if (t >= m) return;
+  const double beta = F[0], s11 = F[1];
+  const double u = 1.0 - z1w;
+  double mean = beta + (zyw - beta * z1w);
+  double var = a.sigma2 * (1.0 - ww + u * u / s11);
+  if (F[2] != 0.0) mean = var = __longlong_as_double(0x7ff8000000000000LL);
+  a.mean[(a.draw0 + b) + (size_t)t * a.S] = mean;
+  a.var[(a.draw0 + b) + (size_t)t * a.S] = var;
+}
+
+static dim3 site_grid(int nbatch, int ns, int* wpb) {
+  *wpb = nbatch < 4 ? nbatch : 4;                                  // waves (site batches) per workgroup
+  return dim3((nbatch + *wpb - 1) / *wpb, ns);
+}
+static void launch_site_corr(hipStream_t s, const SiteArgs& a, int ns) {
+  int wpb;
+  const dim3 grid = site_grid(a.nbatch, ns, &wpb), block(64 * wpb);
+  const size_t lds = site_corr_lds_bytes(a.n, a.d, a.K, wpb);
+  static unsigned long long attr_mask = 0;
+  once_per_device(attr_mask, [] {
+    raise_lds_limit((const void*)site_corr_kernel<1>, "site_corr_kernel");
+    raise_lds_limit((const void*)site_corr_kernel<2>, "site_corr_kernel");
+    raise_lds_limit((const void*)site_corr_kernel<3>, "site_corr_kernel");
+  });
+  if (a.K == 1) hipLaunchKernelGGL(site_corr_kernel<1>, grid, block, lds, s, a);
+  else if (a.K == 2) hipLaunchKernelGGL(site_corr_kernel<2>, grid, block, lds, s, a);
+  else hipLaunchKernelGGL(site_corr_kernel<3>, grid, block, lds, s, a);
+}
+template <int NPF>
+static void launch_site_solve(hipStream_t s, const SiteArgs& a, int ns) {
+  int wpb;
+  const dim3 grid = site_grid(a.nbatch, ns, &wpb), block(64 * wpb);
+  static unsigned long long attr_mask = 0;
+  once_per_device(attr_mask, [] { raise_lds_limit((const void*)site_solve_kernel<NPF>, "site_solve_kernel"); });
+  hipLaunchKernelGGL(site_solve_kernel<NPF>, grid, block, sizeof(double) * site_solve_lds_doubles<NPF>(a.n), s, a);
+}
+
 }  // namespace
+
+// Can predict.post tables of this shape go through the kept-factor scheme (else: the extra-row scheme of rounds 2 - 4)?
+bool small_reg_sites_supported(int n, int d, int K) {
+  if (n > 104 || K > 3) return false;
+  const int nb8 = (n + 7) / 8, npf = fac_npf(n);
+  return sizeof(double) * (kSmallExpTable + (size_t)d * n + (size_t)4 * kPerMat(8 * nb8, 8, 1, K, d)) <= (size_t)kLdsBytes - 64 &&
+         sizeof(double) * ((size_t)FacLayout(n).head + 32 * (npf / 8) * (npf / 8) + 8) <= (size_t)kLdsBytes / 2 - 64 &&   // two per CU
+         site_corr_lds_bytes(n, d, K, 4) <= (size_t)kLdsBytes / 2 - 64;
+}
+// scratch per draw (bytes): the factor block + the correlation vectors of its ceil(m / 64) site batches
+size_t small_reg_sites_scratch(int n, int d, int K, int m) {
+  (void)d; (void)K;
+  return sizeof(double) * ((size_t)FacLayout(n).total + (size_t)((m + 63) / 64) * fac_npf(n) * 64);
+}
 
 constexpr int kPredictNE = 4;   // extra row-blocks of the prediction instances: 30 (G = 8) / 62 (G = 16) sites per chunk
 
@@ -727,14 +1074,62 @@ void launch_small_reg_logdet_designs(hipStream_t s, const double* Xs, int n, int
   dispatch(s, a);
 }
 
-// predict.post for S draws x m test sites (mean / var are S x m column-major)
+// predict.post for S draws x m test sites (mean / var are S x m column-major).  scratch (scratch_bytes, may be null): with at
+// least small_reg_sites_scratch() bytes per draw of a chunk the kept-factor scheme runs (one factorisation per draw, then
+// lane = test site); otherwise the extra-row scheme.
 void launch_small_reg_predict(hipStream_t s, const double* X, int n, int d, const double* y, DrawView dv,
                               int S, const double* Xtest, int m, double sigma2, double* mean, double* var,
-                              double* beta, int* status) {
+                              double* beta, int* status, void* scratch, size_t scratch_bytes, hipStream_t aux,
+                              hipEvent_t ev_fork, hipEvent_t ev_join) {
   RegArgs a{};
   a.X = X; a.y = y; a.n = n; a.d = d; a.params = dv.params; a.ldp = dv.ldp; a.K = dv.K;
   a.draw0 = 0; a.B = S; a.sigma2 = sigma2; a.mode = 0; a.tau2 = 0.0;
   a.beta = beta; a.status = status; a.Xt = Xtest; a.m = m; a.S = S; a.mean = mean; a.var = var;
+  const size_t per = small_reg_sites_scratch(n, d, dv.K, m);
+  if (scratch && small_reg_sites_supported(n, d, dv.K) && scratch_bytes >= per) {
+    const FacLayout fl(n);
+    const int nbatch = (m + 63) / 64;
+    const int chunk = (int)std::min<size_t>((size_t)S, std::min<size_t>(scratch_bytes / per, 32768));
+    double* fac = static_cast<double*>(scratch);
+    double* rs = fac + (size_t)chunk * fl.total;
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+      const int ns = std::min(chunk, S - s0);
+      SiteArgs sa{fac, (size_t)fl.total, X, dv.params, dv.ldp, n, d, dv.K, Xtest, m, S, s0, sigma2, mean, var, rs, nbatch, fl.npf};
+      // the correlation vectors need nothing from the factorisation: on the second stream beside it (the factorisation is ONE
+      // wave per draw -- 1000 draws leave three quarters of the wave slots empty -- and runs at the latency of its n columns)
+      if (aux && ev_fork && ev_join) {
+        (void)hipEventRecord(ev_fork, s);
+        (void)hipStreamWaitEvent(aux, ev_fork, 0);
+        launch_site_corr(aux, sa, ns);
+        (void)hipEventRecord(ev_join, aux);
+      } else {
+        launch_site_corr(s, sa, ns);
+      }
+      RegArgs f = a;
+      f.Xt = nullptr; f.m = 0; f.mean = f.var = nullptr;
+      f.draw0 = s0; f.B = ns;
+      f.fac = fac - (size_t)s0 * fl.total;     // the kernel indexes the block by the draw's global number
+      f.fac_stride = (size_t)fl.total;
+      dispatch<1>(s, f);
+      if (aux && ev_fork && ev_join) (void)hipStreamWaitEvent(s, ev_join, 0);
+      switch (fl.npf / 8) {
+        case 1: launch_site_solve<8>(s, sa, ns); break;
+        case 2: launch_site_solve<16>(s, sa, ns); break;
+        case 3: launch_site_solve<24>(s, sa, ns); break;
+        case 4: launch_site_solve<32>(s, sa, ns); break;
+        case 5: launch_site_solve<40>(s, sa, ns); break;
+        case 6: launch_site_solve<48>(s, sa, ns); break;
+        case 7: launch_site_solve<56>(s, sa, ns); break;
+        case 8: launch_site_solve<64>(s, sa, ns); break;
+        case 9: launch_site_solve<72>(s, sa, ns); break;
+        case 10: launch_site_solve<80>(s, sa, ns); break;
+        case 11: launch_site_solve<88>(s, sa, ns); break;
+        case 12: launch_site_solve<96>(s, sa, ns); break;
+        default: launch_site_solve<104>(s, sa, ns); break;
+      }
+    }
+    return;
+  }
   dispatch<kPredictNE>(s, a);
 }
 
@@ -744,7 +1139,9 @@ static void dispatch(hipStream_t s, const RegArgs& a) {
   // A handful of evaluations (Metro's one proposal per logpost call, a speculative batch of a few candidates) is a
   // LATENCY problem: one wave per matrix leaves the chip empty and runs the whole elimination on 64 lanes; the
   // 16 x 16 grid puts four waves on each matrix (n = 64, one evaluation: 41 -> 25 us of kernel time).
-  const bool wide = NE == 1 && a.x_stride == 0 && a.B <= 64;
+  // (with the factor kept -- prediction -- the four-wave form up to 2048 draws: its one factorisation per draw is the critical
+  // path of the call and a wave per SIMD is all that 1000 draws fill anyway)
+  const bool wide = NE == 1 && a.x_stride == 0 && a.B <= (a.fac ? CCGP_FAC_WIDE_MAX : 64);
   if constexpr (NE == 1) {
     // 64 < n <= 104 (BASELINE config 3: maximin-100): still ONE WAVE per matrix on the 8 x 8 grid, with up to 13 x 13
     // blocks per thread (two waves per SIMD: up to 256 VGPRs) -- at n = 100 1.68 x the minimal FMAs instead of the

@@ -106,6 +106,10 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           fall back to (same bits: the tests hold one against the other)
  *   CCGP_OPT_SMALL_GRID16   0 (default) = 64 < n <= 104 runs ONE wave per matrix on the 8 x 8 thread grid (up to 13 x 13
  *                           blocks per thread); 1 = the 16 x 16 grid (one workgroup per matrix) of rounds 1 - 3 (same bits)
+ *   CCGP_OPT_PREDICT_FACTOR 1 (default) = prediction tables at n <= 104 (K <= 3) factorise each draw ONCE, keep the factor in HBM
+ *                           and solve for the test sites with one lane per site; 0 = the extra-row scheme of rounds 2 - 4 (the
+ *                           test sites ride through the elimination in chunks of 30 / 62, one factorisation per chunk): same
+ *                           bits, the tests hold one against the other
  *   CCGP_OPT_SCHED          the blocked Cholesky sweep of a chunk (n > 128): 0 = one launch per phase and block column
  *                           (rounds 1 - 4); 1 = ONE persistent launch whose workgroups take diagonal / update / panel-solve
  *                           tiles from dependency-driven queues, two workgroups per CU; 2 = the same with one workgroup per CU;
@@ -120,7 +124,7 @@ int ccgp_set_workspace_limit(ccgp_handle* h, size_t bytes);
  *                           matrix 0's second block column, so that the sweep cannot finish -- it must then abort after
  *                           CCGP_SCHED_TIMEOUT_MS (environment, default 30000) and fail every evaluation of the chunk, not hang */
 enum { CCGP_OPT_FUSE_DIAG = 2, CCGP_OPT_TAIL_STRIPS = 3, CCGP_OPT_WIDE_OFFSETS = 4, CCGP_OPT_SMALL_GRID16 = 5,
-       CCGP_OPT_SCHED = 7, CCGP_OPT_SCHED_POLICY = 8 };
+       CCGP_OPT_SCHED = 7, CCGP_OPT_SCHED_POLICY = 8, CCGP_OPT_PREDICT_FACTOR = 9 };
 int ccgp_set_option(ccgp_handle* h, int option, int value);
 /* pre-size scratch so that later _dev calls of this shape never allocate */
 int ccgp_reserve(ccgp_handle* h, int n, int d, int K, int B, int m);

@@ -1145,3 +1145,70 @@ def test_small_n_gradient_pass_structure(handle, n, d, K):
     assert ll[0] == pytest.approx(orc.loglik_general(X, y, w, T, 0.8)[0], rel=1e-9)
     fd = orc.loglik_grad_fd(X, y, row, K, d, 0.8)
     np.testing.assert_allclose(grad[0], fd, rtol=5e-5, atol=5e-5 * np.abs(fd).max())
+
+
+# ------------------------------------------------------------------------------- a10 / a11: kept-factor prediction (round 5)
+@pytest.mark.parametrize("n,d,K,S,m", [(8, 1, 2, 5, 3), (20, 3, 1, 30, 70), (50, 9, 2, 120, 150), (64, 4, 2, 100, 14), (65, 2, 3, 40, 129),
+                                       (90, 9, 2, 150, 110), (100, 2, 2, 64, 200), (104, 5, 3, 33, 65)])
+def test_kept_factor_prediction_has_the_bits_of_the_extra_row_scheme(handle, n, d, K, S, m):
+    """predict.post tables (HX:655-673 over HX:686-725) at n <= 104: since round 5 each draw is factorised ONCE (the likelihood
+    kernel keeps L', 1/d, z'_y, z'_1 in HBM), the test sites' correlation vectors are formed beside it on a second stream
+    (lane = site) and a third kernel does the forward substitutions (lane = site, L' by broadcast LDS reads).  Rounds 2 - 4
+    carried the sites through the elimination as extra rows, 30 / 62 per factorisation.  Every (draw, site) entry sees the same
+    operations in the same order under both, so mean, variance, beta and status agree bit for bit -- including a draw whose
+    matrix cannot be factorised -- and both agree with the oracle."""
+    from ccgp_amd import api
+    rng = np.random.default_rng(1000 * n + m)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(2 * np.pi * X).sum(axis=1)
+    P = np.empty((S, K + K * d))
+    for b in range(S):
+        w = 0.15 + 0.55 * rng.dirichlet(np.ones(K))
+        th = np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(K, d)))
+        th[K - 1] = np.maximum(th[K - 1], 25.0)
+        P[b] = np.concatenate([w, th.ravel()])
+    P[S // 2, K:] = 1e-5
+    Xt = rng.uniform(size=(m, d))
+    res = {}
+    for opt in (0, 1):
+        handle.set_option(api.OPT_PREDICT_FACTOR, opt)
+        try:
+            res[opt] = handle.predict_batch(X, y, K, P, Xt, 1.7)
+        finally:
+            handle.set_option(api.OPT_PREDICT_FACTOR, 1)
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    st = np.asarray(res[1][3])
+    assert (st != 0).sum() <= 2 and np.isnan(res[1][0][st != 0]).all() and np.isfinite(res[1][0][st == 0]).all()
+    if d < 9:
+        assert st[S // 2] != 0          # the nearly constant correlation matrix is singular to working precision
+    b = 0 if S // 2 else 1
+    w, Th = orc.unpack_params(P[b], K, d)
+    R_inv = orc.solve_inverse(orc.mixed_corr_matrix_general(X, w, Th))
+    beta = orc.beta_mle(R_inv, y)
+    mf, v1, v2 = orc.factors(R_inv, beta, y)
+    for t in (0, m - 1):
+        mean, var = orc.predict_post_from_factors(orc.mixed_corr_vec_general(Xt[t], X, w, Th), beta, mf, v1, v2, R_inv, 1.7)
+        assert res[1][0][b, t] == pytest.approx(mean, rel=1e-7, abs=1e-8)
+        assert res[1][1][b, t] == pytest.approx(var, rel=1e-5, abs=1e-8)
+
+
+def test_kept_factor_prediction_in_chunks_of_draws(handle):
+    """The factor blocks and correlation vectors live in the handle's workspace; when the limit does not hold them for every
+    draw the call runs in chunks of draws -- same bits."""
+    from ccgp_amd import api
+    rng = np.random.default_rng(5)
+    n, d, K, S, m = 50, 4, 2, 300, 150
+    X = rng.uniform(size=(n, d))
+    y = np.cos(3 * X).sum(axis=1)
+    P = np.column_stack([rng.uniform(0.3, 0.9, S), np.zeros(S), np.exp(rng.uniform(-1, 2, size=(S, d))), np.full((S, d), 30.0)])
+    P[:, 1] = 1 - P[:, 0]
+    Xt = rng.uniform(size=(m, d))
+    whole = handle.predict_batch(X, y, K, P, Xt, 1.0)
+    handle.set_workspace_limit(20 << 20)        # ~ 100 KB per draw: chunks of about a hundred
+    try:
+        chunked = handle.predict_batch(X, y, K, P, Xt, 1.0)
+    finally:
+        handle.set_workspace_limit(200 << 30)
+    for a, b in zip(whole, chunked):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))

@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r04/pmc_traffic.json", "r04/pmc_traffic64.json", "r03/pmc_traffic.json", "r03/pmc_traffic64.json", "r02n/pmc_traffic.json", "r02n/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
+PMC_TRAFFIC_FILES = ("r05/pmc_traffic.json", "r05/pmc_traffic64.json", "r05/pmc_traffics1.json", "r04/pmc_traffic.json", "r04/pmc_traffic64.json", "r03/pmc_traffic.json", "r03/pmc_traffic64.json", "r02n/pmc_traffic.json", "r02n/pmc_traffic64.json")   # latest committed rocprofv3 --pmc passes of this bench command
 
 
 # ----------------------------------------------------------------------------- synthetic inputs
@@ -162,6 +162,29 @@ def pmc_traffic(kernel, matrices_per_launch):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
+def effective_cpus():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box of the pool
+    shows all 256 hardware threads of its host to os.cpu_count() but grants a one-GPU job 16 CPUs' worth of time; rounds 2 - 4
+    started one OpenMP thread per VISIBLE thread and read the quota as "6 % parallel efficiency")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        n = min(n, max(1, int(math.ceil(q / int(fh2.read())))))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -179,7 +202,7 @@ def cpu_compiled_loglik(X, y, P, K, sigma2, mode, tau2, per_core, one_core_evals
     evaluation per core, on every core of this host and on one core.  Bounded sample of the workload's draws.
     in_process_all=False (large n): only the one-core figure; the all-cores figure then comes from cpu_process_sweep."""
     from oracle.cpu_baseline import loader as cpu
-    cores = cpu.max_threads()
+    cores = min(cpu.max_threads(), effective_cpus())
     B, t_all = 0, float("nan")
     if in_process_all:
         B = min(P.shape[0], per_core * cores)
@@ -212,7 +235,7 @@ def cpu_gradient_fd(X, y, P, K, sigma2, per_core=100):
     logpost numerically (HX:493) -- so the baseline is the compiled evaluator with CENTRAL DIFFERENCES in every parameter
     (2 P likelihood evaluations per gradient), OpenMP over evaluations on every core."""
     from oracle.cpu_baseline import loader as cpu
-    cores = cpu.max_threads()
+    cores = min(cpu.max_threads(), effective_cpus())
     B = min(P.shape[0], per_core * cores)
     Pn = P.shape[1]
     h = 1e-4     # relative step: the likelihood itself carries cond(R) eps of rounding, so smaller steps only add noise
@@ -252,7 +275,7 @@ def cpu_reference_opcount(workload, X, y, P, K, sigma2, mode, tau2, budget_s=8.0
 def cpu_predict_sample(sets, P5, draws_per_core=8):
     """cfg5 on the CPU: the compiled evaluator's predict.post tables for a bounded number of draws of every set."""
     from oracle.cpu_baseline import loader as cpu
-    cores = cpu.max_threads()
+    cores = min(cpu.max_threads(), effective_cpus())
     S = min(P5.shape[0], draws_per_core * cores)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 1.0:                 # warm-up of the OpenMP team (see cpu_compiled_loglik)
@@ -337,10 +360,8 @@ def cpu_process_sweep(X, y, P, K, sigma2, mode, tau2, evals_per_worker=2, budget
     Wall time from "go" to the last worker's "done"; workers load and warm up before."""
     import subprocess
     import tempfile
-    H = os.cpu_count() or 1
-    ts = [t for t in (1, 2, 4, 8, 16, 32, 64) if t <= H and H // t >= 1]
-    if H >= 128:
-        ts = [t for t in ts if t >= 1]       # OpenBLAS builds cap at 64 threads per call
+    H = effective_cpus()
+    ts = [t for t in (64, 32, 16, 8, 4, 2, 1) if t <= H]      # fewest processes first: the cheap configurations before the budget runs out
     worker = os.path.join(ROOT, "oracle", "cpu_baseline", "cpu_worker.py")
     rows, t_start = [], time.perf_counter()
     with tempfile.TemporaryDirectory() as td:
@@ -1040,7 +1061,7 @@ def cfg4_predict_sites(d):
 def cpu_predict_n4096(X, y, K, P, sigma2):
     """The compiled CPU evaluator on the factor-set workload (n = 4096, 16 draws x 128 sites: one draw per core)."""
     from oracle.cpu_baseline import loader as cpu
-    cores = cpu.max_threads()
+    cores = min(cpu.max_threads(), effective_cpus())
     Xt = cfg4_predict_sites(X.shape[1])
     t0 = time.perf_counter()
     cpu.predict_batch(X, y, K, P, Xt, sigma2, threads=cores)
@@ -1053,7 +1074,7 @@ def cpu_predict_n4096(X, y, K, P, sigma2):
 def cpu_gradient_n4096(X, y, K, row, sigma2):
     """ONE gradient at n = 4096 by central differences of the compiled evaluator: 2 P evaluations, one per core."""
     from oracle.cpu_baseline import loader as cpu
-    cores = cpu.max_threads()
+    cores = min(cpu.max_threads(), effective_cpus())
     Pn = row.size
     hstep = 1e-5
     big = np.repeat(row[None], 2 * Pn, axis=0)

@@ -143,6 +143,9 @@ void small_reg_kernel(RegArgs a) {
   constexpr int XR = G * NE;       // extra rows (y', 1', then test sites)
   constexpr int MT = XR - 2;       // test sites per chunk
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  // the factorisation a prediction waits for is ONE wave per draw running at the latency of its n columns, with the site
+  // correlation kernel's waves issuing beside it on the same SIMDs: it goes first
+  if constexpr (FAC) __builtin_amdgcn_s_setprio(3);
   const int n = a.n, d = a.d, K = a.K;
   const int PM = kPerMat(NP, G, NE, K, d, INV != 0);
   const int tid = threadIdx.x, sub = tid / TPM, lt = tid % TPM;

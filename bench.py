@@ -351,7 +351,7 @@ def cpu_predict_post_latency(X, y, x_new, sigma2, calls=200):
             "compiled_matches_numpy": bool(np.allclose(got, np.ravel(want), rtol=1e-9, atol=1e-12))}
 
 
-def cpu_process_sweep(X, y, P, K, sigma2, mode, tau2, evals_per_worker=2, budget_s=60.0):
+def cpu_process_sweep(X, y, P, K, sigma2, mode, tau2, evals_per_worker=6, budget_s=60.0):
     """All-cores figure for LARGE n as a sweep over (concurrent evaluations c) x (threads per evaluation t), c t = the host's
     hardware threads: c worker processes (oracle/cpu_baseline/cpu_worker.py), each evaluating one draw at a time with t
     threads (OpenMP over the covariance columns, OpenBLAS dpotrf / dtrsv with t threads).  Processes, because scipy's

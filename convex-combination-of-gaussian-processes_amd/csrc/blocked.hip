@@ -2127,7 +2127,9 @@ struct GroupRun {
     return (nt >= 16 && nb >= 32 && nb <= 128) ? 2 : 0;
   }
   bool scheduled() const {
-    return sched_mode() != 0 && h->opt_fuse_diag && sched::rows(sched::Shape{nt, w.ne, 0}) < 0x7fff &&
+    // a workgroup serves the queue of the XCD it runs on and matrix b lives on queue b % 8: the whole chip in one partition
+    // (8 XCDs x 32 CUs) -- on a partitioned device some queues would have no workgroup and the sweep would end in the abort path
+    return sched_mode() != 0 && h->n_cus == 256 && h->opt_fuse_diag && sched::rows(sched::Shape{nt, w.ne, 0}) < 0x7fff &&
            (size_t)nb * (size_t)sched::tasks_per_matrix(sched::Shape{nt, w.ne, 0}) < 0x7fffffffull;
   }
   void sweep_scheduled() {

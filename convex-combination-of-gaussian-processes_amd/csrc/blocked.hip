@@ -1136,301 +1136,7 @@ CCGP_DEFINE_GEMM(chol_update_s2_kernel, 0, 2, 2)
 CCGP_DEFINE_GEMM(chol_trsm_kernel, 1, 1, 2)
 #undef CCGP_DEFINE_GEMM
 
-// ---- dataflow scheduler: the whole sweep of a chunk as ONE persistent launch --------------------------------------------
-// Round 5.  Instead of one update and one trsm launch per block column, workgroups take tiles -- D(j): diagonal workgroup,
-// U(i, j): whole update tile, T(i, j): panel-solve tile -- from per-XCD FIFO queues that finished tiles fill
-// (sched_logic.h has the dependency rules and the progress argument).  Tiles run the SAME device code in the same k order
-// as the launches (gemm_unit / diag_unit), so the bits do not change; what changes is that nothing waits for the slowest
-// workgroup of a launch: a matrix whose block column is done goes on while others are still in it, the panel solves
-// (HBM-bound when all 256 CUs run them at once) and the short-K updates of the first block columns mix with MFMA-bound
-// tiles of other matrices, and 63 launch boundaries disappear.
-//   pop    : idx = head[q]++ ; wait until slot idx of queue q is non-zero (bounded: a dependency bug sets the abort flag and
-//            every workgroup leaves -- the sweep then reports failure for the chunk instead of hanging the device)
-//   finish : every wave releases its stores at agent scope, barrier, then wave 0 applies the arrivals (one lane per row for the
-//            fan-outs of a diagonal block and of a pivot-row solve) and stores the tasks that became ready
-// Synchronisation, two forms (policy bit 1):
-//   agent (0) : the HSA memory model as the compiler implements it -- release fence (agent) -> relaxed RMW / store on one side,
-//               relaxed load -> acquire fence (agent) on the other; a counter's last arriver fences acq_rel between its RMW and
-//               its announcement.  On this chip an agent-scope acquire is `buffer_inv sc1` and a release `buffer_wbl2 sc1`: every
-//               task invalidates and writes back the L2 of its XCD, the column panel that a matrix's tiles share through that L2
-//               is re-read from HBM by every tile, and the sweep takes 269 ms instead of 189 (profiles/r05_experiments.md).
-//   xcd (1, default) : everything that touches a matrix runs on ONE XCD (its queue is served by that XCD's workgroups only: no
-//               stealing), so producer and consumer share the L2 and only the per-CU L1 stands between them.  L1 is write-through:
-//               `s_waitcnt vmcnt(0)` = the stores are in L2; `buffer_inv sc0` drops the consumer's L1 lines; counters and queue
-//               words are L2 atomics / L1-bypassing loads.  The queues of XCDs that got no workgroup would never drain: the check
-//               kernel fails the chunk unless every queue announced all of its tasks.
-// Placement: a workgroup serves the queue of the XCD it runs on (XCC_ID), so a matrix's tiles share the column panel in one
-// L2 as they do under the launches' blockIdx % 8 rule; in agent form a workgroup whose queue is handed out moves on to the next
-// one.  Two workgroups fit a CU; with `policy` bit 0 the second one of a CU only takes work while a backlog exists
-// (tail > head), so that a few ready tiles spread over the CUs instead of pairing up.
-struct SchedArgs {
-  GemmArgs g;
-  int* ctrl;                     // [q * 16 + 0] head, [+1] tail, [+2] tasks of queue q, [+3] slot offset, [+4] tasks finished; [128] abort
-  unsigned long long* slots;
-  int* counters;                 // nb x counters_per_matrix
-  int* cu_seen;                  // [8 * 128]: workgroups that registered on each CU
-  int policy;
-  int backlog_min;               // policy bit 0: a CU's second workgroup takes (or chains) a task only while at least this many wait in its queue
-  unsigned timeout_10ns;         // a wait longer than this aborts the sweep
-  unsigned long long* prof;      // policy bit 2: per workgroup 8 words (10 ns ticks): waiting for a task, D, U, T tiles, arrivals; tasks, XCD, second-on-its-CU
-};
-constexpr int kSchedCtrlInts = 256;
-constexpr int kSchedProfWgs = 1024, kSchedProfWords = 8;
-
-__device__ __forceinline__ int sched_ld(const int* p) {   // sc1 load: never served by the L1
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sched_acquire(bool xcd) {
-  if (xcd) asm volatile("buffer_inv sc0" ::: "memory");
-  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__device__ __forceinline__ void sched_release(bool xcd) {
-  if (xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-}
-__device__ __forceinline__ void sched_acq_rel(bool xcd) {
-  if (xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-}
-
-// thread 0: next task word of this workgroup, or 0 when its queue(s) are finished (or the sweep was aborted).
-// A queue is finished when all of its tasks are DONE (ctl[4] == N): tasks that a workgroup chained to the one it had just
-// finished never pass through a slot, so fewer than N slots are ever filled and the holders of the others leave on that count.
-__device__ inline unsigned long long sched_pop(const SchedArgs& a, int& q, int& left, int secondary) {
-  const bool xcd = (a.policy & 2) != 0;
-  while (left > 0) {
-    int* ctl = a.ctrl + q * 16;
-    const int N = ctl[2];
-    unsigned long long t0 = 0;
-    unsigned polls = 0;
-    auto overdue = [&]() {   // every 256 polls: abort flag, and the clock (100 MHz)
-      if ((++polls & 255u) != 0) return false;
-      if (sched_ld(a.ctrl + 128)) return true;
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      if (t0 == 0) t0 = now;
-      if (now - t0 > (unsigned long long)a.timeout_10ns) {
-        __hip_atomic_store(a.ctrl + 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return true;
-      }
-      return false;
-    };
-    bool live = N > 0;
-    if (live && secondary) {
-      for (;;) {
-        if (sched_ld(ctl + 4) >= N) { live = false; break; }
-        if (sched_ld(ctl + 1) - sched_ld(ctl) >= a.backlog_min) break;
-        if (overdue()) return 0;
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    if (live) {
-      const int idx = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (idx < N) {
-        const unsigned long long* slot = a.slots + (size_t)ctl[3] + idx;
-        for (;;) {
-          const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (w) {
-            sched_acquire(xcd);
-            return w;
-          }
-          if ((polls & 7u) == 7u && sched_ld(ctl + 4) >= N) break;   // everything is done: this slot stays empty
-          if (overdue()) return 0;
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-    }
-    if (xcd) return 0;   // no stealing: another XCD's tiles must not pass through this L2
-    q = (q + 1) & 7;
-    --left;
-  }
-  return 0;
-}
-
-// wave 0 after the tile's stores are released: arrivals and announcements (sched_logic.h: finish, with the two fan-outs
-// spread over the lanes).  Returns (lane 0) the task this workgroup goes on with itself -- the first one its arrivals made
-// ready, in the order of urgency: the next diagonal block, the pivot row's solve, the row's own next tile -- or 0.
-__device__ inline unsigned long long sched_finish(const SchedArgs& a, const sched::Shape& s, unsigned long long w, int lane, bool chain) {
-  const int kind = sched::task_kind(w), j = sched::task_j(w), i = sched::task_i(w), b = sched::task_b(w);
-  const int R = sched::rows(s);
-  const bool xcd = (a.policy & 2) != 0;
-  int* c = a.counters + (size_t)b * sched::counters_per_matrix(s);
-  int* ctl = a.ctrl + (b & 7) * 16;
-  unsigned long long* slots = a.slots + (size_t)ctl[3];
-  unsigned long long next = 0;
-  auto add = [&](int idx, int inc) { return __hip_atomic_fetch_add(c + idx, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto raise = [&](int idx, int level) {   // hi = max(hi, level) in one atomic step; the word it replaced (or met)
-    int old = __hip_atomic_load(c + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (sched::hi16(old) < level &&
-           !__hip_atomic_compare_exchange_strong(c + idx, &old, (level << 16) | sched::lo16(old), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)) {}
-    return old;
-  };
-  auto emit = [&](int k2, int j2, int i2) {
-    if ((a.policy & 16) && b == 0 && k2 == sched::kT && j2 == 1) return;   // test hook: lose matrix 0's block column 1 (the abort path)
-    if (chain && lane == 0 && next == 0) {
-      next = sched::encode(k2, j2, i2, b);
-      return;
-    }
-    const int pos = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slots + pos, sched::encode(k2, j2, i2, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  const bool pivot = sched::is_pivot_solve(s, kind, j, i);
-  if (kind == sched::kD || pivot) {
-    // one lane per row, 64 rows per pass: the row's update, the fence, its announcement (sched_logic.h: row_after_D /
-    // row_after_pivot; the level a row announces is the one IT was waiting for, which a fan-out that overtook another may
-    // find below its own)
-    if (pivot) {                                          // D(j+1) first: it is the longest task that follows
-      bool rd = false;
-      if (lane == 0) rd = sched::lo16(add(2 * R, 1 << 16)) >= j + 1;
-      sched_acq_rel(xcd);
-      if (rd) emit(sched::kD, j + 1, j + 1);
-    }
-    const int r0 = kind == sched::kD ? j + 1 : j + 2;
-    for (int rb = r0; rb < R; rb += 64) {                 // wave-uniform trip count: the fence below is executed by every lane
-      const int r = rb + lane;
-      int jn = -1;
-      if (r < R) jn = kind == sched::kD ? sched::row_after_D(s, j, r, raise) : sched::row_after_pivot(s, j, r, raise);
-      sched_acq_rel(xcd);
-      if (jn >= 0) emit(kind == sched::kD ? sched::kT : sched::kU, jn, r);
-    }
-  } else if (lane == 0) {
-    // one arrival, at most one announcement: the shared single-thread rule, with the fence between the two
-    int ak = 0, aj = 0, ai = 0;
-    sched::finish_single(s, kind, j, i, add, [&](int k2, int j2, int i2) { ak = k2; aj = j2; ai = i2; });
-    sched_acq_rel(xcd);
-    if (ak) emit(ak, aj, ai);
-  }
-  if (lane == 0) (void)__hip_atomic_fetch_add(ctl + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // after the announcements
-  return next;
-}
-
-__device__ __forceinline__ void sched_run(const GemmArgs& g, double* smem, unsigned long long w) {
-  const int kind = sched::task_kind(w), j = sched::task_j(w), i = sched::task_i(w), b = sched::task_b(w);
-  if (kind == sched::kD) {
-    if (j == 0) {
-      DiagArgs dg{g.A, g.a_stride, g.npad, g.invd, g.invd_stride, g.logdet_part, g.status, 0, g.nt, g.nb, g.n, g.ld, g.ptol};
-      diag_factor(dg, b, smem);
-    } else {
-      diag_unit(g, smem, j, b);
-    }
-  } else if (kind == sched::kU) {
-    gemm_unit<0, 1>(g, smem, j, b, i, 0, false);
-  } else {
-    gemm_unit<1, 1>(g, smem, j, b, i, 0, false);
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void chol_sched_kernel(SchedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ unsigned long long s_task, s_next, s_acc[6];   // thread 0's state lives in LDS: registers are the tiles'
-  const int tid = threadIdx.x;
-  const sched::Shape shp{a.g.nt, a.g.ne, a.g.extra_lower};
-  int q = 0, left = 8, secondary = 0;
-  const bool xcd = (a.policy & 2) != 0;
-  if (tid == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7;      // XCC_ID
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID: cu [11:8], sh [12], se [15:13]
-    const int seen = __hip_atomic_fetch_add(a.cu_seen + xcc * 128 + ((hw >> 8) & 127), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    q = (int)xcc;
-    secondary = (a.policy & 1) && seen > 0;
-  }
-  const bool prof = (a.policy & 4) && a.prof && blockIdx.x < kSchedProfWgs;
-  const bool chaining = (a.policy & 8) != 0;
-  if (tid == 0) {
-    s_next = 0;   // the task this workgroup chained to the one it finished
-    for (int e = 0; e < 6; ++e) s_acc[e] = 0;
-  }
-  for (;;) {
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
-    if (prof && tid == 0) t0 = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) {
-      const unsigned long long nx = s_next;
-      s_task = nx ? nx : sched_pop(a, q, left, secondary);
-    }
-    __syncthreads();
-    const unsigned long long wv = s_task;
-    const unsigned long long w = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(wv >> 32)) << 32) |
-                                 (unsigned)__builtin_amdgcn_readfirstlane((int)wv);
-    if (w == 0) break;
-    sched_acquire(xcd);   // every wave: what the producers released is read afresh
-    if (prof && tid == 0) t1 = __builtin_amdgcn_s_memrealtime();
-    sched_run(a.g, smem, w);
-    sched_release(xcd);   // every wave: its stores are out (in L2, or device-wide) before the barrier
-    __syncthreads();
-    if (prof && tid == 0) t2 = __builtin_amdgcn_s_memrealtime();
-    if (tid < 64) {
-      bool chain = chaining;
-      if (chain && secondary) {   // a CU's second workgroup goes on only while its queue has a backlog
-        const int* ctl = a.ctrl + (sched::task_b(w) & 7) * 16;
-        chain = sched_ld(ctl + 1) - sched_ld(ctl) >= a.backlog_min;
-      }
-      const unsigned long long nx = sched_finish(a, shp, w, tid, chain);
-      if (tid == 0) s_next = nx;
-    }
-    if (prof && tid == 0) {
-      s_acc[0] += t1 - t0;
-      s_acc[sched::task_kind(w)] += t2 - t1;
-      s_acc[4] += __builtin_amdgcn_s_memrealtime() - t2;
-      s_acc[5] += 1;
-    }
-  }
-  if (prof && tid == 0) {
-    unsigned long long* o = a.prof + (size_t)blockIdx.x * kSchedProfWords;
-    for (int e = 0; e < 6; ++e) o[e] = s_acc[e];
-    o[6] = (unsigned long long)q;
-    o[7] = (unsigned long long)secondary;
-  }
-}
-
-// counters, queue heads / tails / sizes / offsets, seeds D(0) and empty slots for one sweep
-struct SchedInitArgs {
-  int* ctrl;
-  unsigned long long* slots;
-  int* counters;
-  int* cu_seen;
-  int nb, nt, ne, lower;
-  long tasks_per_matrix;
-  long total_slots;
-};
-__global__ __launch_bounds__(256) void sched_init_kernel(SchedInitArgs a) {
-  const sched::Shape s{a.nt, a.ne, a.lower};
-  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
-  const int cpm = sched::counters_per_matrix(s);
-  // matrices of queue q: b = q, q + 8, ...; its slots start at off(q)
-  auto nmat = [&](int q) { return a.nb > q ? (a.nb - q + 7) / 8 : 0; };
-  auto off = [&](int q) { long o = 0; for (int x = 0; x < q; ++x) o += nmat(x) * a.tasks_per_matrix; return o; };
-  for (long e = tid; e < a.total_slots; e += nth) a.slots[e] = 0;
-  for (long e = tid; e < 8 * 128; e += nth) a.cu_seen[e] = 0;
-  for (long e = tid; e < kSchedCtrlInts; e += nth) {
-    const int q = (int)(e >> 4), f = (int)(e & 15);
-    int v = 0;
-    if (q < 8 && f == 1) v = nmat(q);                                // tail: the seeds
-    if (q < 8 && f == 2) v = (int)(nmat(q) * a.tasks_per_matrix);
-    if (q < 8 && f == 3) v = (int)off(q);
-    a.ctrl[e] = v;
-  }
-  for (long b = tid; b < a.nb; b += nth) sched::init_counters(s, a.counters + b * cpm);
-  __syncthreads();
-  // seeds after the zeroing of THEIR slots: the first nmat(q) slots of a queue are written by the threads below only
-  // (the zeroing loop above skips nothing, so order the two through a second pass: seeds are stored by the same grid-stride
-  // owner that zeroed the slot)
-  for (long e = tid; e < a.total_slots; e += nth) {
-    int q = 0;
-    long o = 0;
-    while (q < 7 && e >= o + nmat(q) * a.tasks_per_matrix) { o += nmat(q) * a.tasks_per_matrix; ++q; }
-    const long k = e - o;
-    if (k < nmat(q)) a.slots[e] = sched::encode(sched::kD, 0, 0, (int)(q + 8 * k));
-  }
-}
-
-// after the sweep: an aborted or incomplete schedule (a queue nobody served) fails every matrix of the chunk (status -> NaN
-// likelihoods, non-zero return code)
-__global__ void sched_check_kernel(const int* ctrl, int* status, int nb) {
-  bool ok = sched_ld(ctrl + 128) == 0;
-  for (int q = 0; q < 8; ++q) ok = ok && sched_ld(ctrl + q * 16 + 4) == ctrl[q * 16 + 2];   // every task of every queue was run
-  if (ok) return;
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) status[b] = 0x7fffffff;
-}
+#include "blocked_sched.inc"   // chol_sched_kernel, sched_init_kernel, sched_check_kernel (round 5)
 
 // Strip count of an update launch: always 1 since round 2.  One workgroup per SIMD-set saturates a CU's four MFMA
 // pipes, so the time of a launch is a step function of its workgroup count in units of 256 (16.3 us per 128-deep

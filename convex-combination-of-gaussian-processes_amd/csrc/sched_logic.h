@@ -1,4 +1,4 @@
-// Dependency logic of the dataflow tile scheduler of the blocked Cholesky sweep (blocked.hip: chol_sched_kernel).
+// Dependency logic of the dataflow tile scheduler of the blocked Cholesky sweep (blocked_sched.inc: chol_sched_kernel).
 // Plain C++ shared by the device kernel, the host (queue sizes, initial counters) and a CPU test that executes the same
 // rules with host threads (tests/host_sched/): every task must be announced exactly once, after everything it reads.
 //
@@ -98,7 +98,7 @@ CCGP_HD inline void init_counters(const Shape& s, int* c) {
 //   add(idx, inc)      fetch-add
 //   raise(idx, level)  hi = max(hi, level), lo untouched (compare-exchange loop; returns the word it saw when hi >= level already)
 // and `announce(kind, j, i)`, which queues a task of the same matrix.  The device kernel runs the two fan-outs with one lane
-// per row (sched_finish in blocked.hip) on the same row rules.
+// per row (sched_finish in blocked_sched.inc) on the same row rules.
 CCGP_HD inline int lo16(int v) { return v & 0xffff; }
 CCGP_HD inline int hi16(int v) { return (v >> 16) & 0xffff; }
 // did raising hi to `level` carry it over lo (the row's waiting task became ready through THIS update)?

@@ -1,4 +1,4 @@
-"""The dataflow tile scheduler of the blocked Cholesky sweep (csrc/blocked.hip: chol_sched_kernel, csrc/sched_logic.h) against
+"""The dataflow tile scheduler of the blocked Cholesky sweep (csrc/blocked_sched.inc: chol_sched_kernel, included by blocked.hip; csrc/sched_logic.h) against
 the launch-per-phase sweep of rounds 1 - 4: SAME tile code and summation order, so every result must agree bit for bit --
 likelihood, beta, status (also of evaluations that fail), prediction tables (extra tile rows), explicit inverse and gradient
 (identity rows, lower-triangular extra block), kept factors.  Then the failure path: a schedule that cannot finish must fail

@@ -1022,7 +1022,7 @@ def end_to_end_fit_item(h):
     out = {"workload": "end-to-end fit: Ground Vibrations sample 1 (n = 50, d = 9): laplace + Metro (1000 retained draws, Geweke "
                        "stopping rule) + prediction at 150 sites, sigma2 = 10.2494 (the value behind the reference's recorded table)"}
     runs = {}
-    for name, m in (("sequential", 0), ("blocks_of_4", 4)):
+    for name, m in (("sequential", 0), ("blocks_of_4", 4), ("blocks_of_6", 6), ("blocks_of_8", 8)):
         calls = {"logpost": 0, "rows": 0, "s": 0.0}
         inner = fit.logpost_batch
 
@@ -1046,7 +1046,8 @@ def end_to_end_fit_item(h):
                       "seconds_in_device_calls": calls["s"], "host_share": 1.0 - calls["s"] / el,
                       "proposals": ch["proposals"], "accepted": ch["accepted"], "rmspe": fit.comparison_summary(table)["rmspe"]}
         runs[name + "_draws"] = table["draws"]
-    out["same_chain"] = bool(np.array_equal(runs.pop("sequential_draws"), runs.pop("blocks_of_4_draws")))
+    seq = runs.pop("sequential_draws")
+    out["same_chain"] = bool(all(np.array_equal(seq, runs.pop(k)) for k in [k for k in runs if k.endswith("_draws")]))
     out.update(runs)
     out["note"] = ("device_calls counts laplace's (one candidate each: Nelder-Mead and the Hessian stencil) and the sampler's; "
                    "host_share = Python host layer (Geweke test, accept / reject walk, prediction summaries) and is what an R host "

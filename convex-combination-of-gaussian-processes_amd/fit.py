@@ -246,13 +246,12 @@ def Metro(gp, start, N, samp_size, batch_size, alpha, D_train, sigma2, y, theta1
             while len(pending) < m:
                 pending.append(draw_pair())
             # level t holds the 2^t candidates reachable after t proposals; history bits: 1 = accepted
-            states, levels = [st["theta"]], []
+            states, levels = np.asarray(st["theta"], dtype=float)[None, :], []
             for t in range(m):
-                e = pending[t][1]
-                cands = [s + e for s in states]
+                cands = states + pending[t][1]              # same additions as the sequential chain: same bits
                 levels.append(cands)
-                states = [x for s, c in zip(states, cands) for x in (s, c)]
-            l_all, b_all = logpost_fn(np.asarray([c for lv in levels for c in lv]))
+                states = np.stack([states, cands], axis=1).reshape(2 * states.shape[0], -1)   # (s0, c0, s1, c1, ...)
+            l_all, b_all = logpost_fn(np.concatenate(levels, axis=0))
             st["batches"] += 1
             idx, off, used = 0, 0, 0
             for t in range(m):

@@ -20,7 +20,7 @@
 #                                  #   instead of S x (5 + 2n + n^2); FALSE: the frame exactly as the script builds it
 #     ccgp.adv.as.written <- FALSE # ADV only: TRUE keeps predict.post's theta1 * (1 + lambda) second scale (ADV:672)
 #                                  #   through the literal per-draw path instead of the training kernel (ADV:417)
-#     ccgp.metro.block <- 4        # Metro evaluates the next 4 iterations' 2^4 - 1 candidates in ONE device call
+#     ccgp.metro.block <- 6        # Metro evaluates the next 6 iterations' 2^6 - 1 candidates in ONE device call
 #                                  #   (same chain, same RNG stream: see Metro below); 1 = the script's own Metro, one logpost
 #                                  #   per proposal
 # Every index into a frame or a frame row is computed in r/ccgp_shim.c (executed by the test-suite), not here.
@@ -31,7 +31,7 @@ dyn.load(Sys.getenv("CCGP_R_SHIM", "ccgpR.so"))
 if (!exists("ccgp.script")) ccgp.script <- "HX"
 if (!exists("ccgp.slim.frame")) ccgp.slim.frame <- TRUE
 if (!exists("ccgp.adv.as.written")) ccgp.adv.as.written <- FALSE
-if (!exists("ccgp.metro.block")) ccgp.metro.block <- 4L
+if (!exists("ccgp.metro.block")) ccgp.metro.block <- 6L
 # ADV as written goes through the literal per-draw predict.post, which reads R.Inv and the factors from every frame row:
 # a slim frame (7 numbers per row) would make every prediction NA, so that option implies the full frame
 if (ccgp.script == "ADV" && ccgp.adv.as.written) ccgp.slim.frame <- FALSE
